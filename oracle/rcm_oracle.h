@@ -1,0 +1,136 @@
+/*
+ * rcm_oracle.h -- CPU ORACLE. TEST INFRASTRUCTURE ONLY.
+ *
+ * Plain-C restatement of the reference's radiative-convective column path
+ * (pabloconrat/our_first_climate_model: main.cpp, repwvl_thermal.cpp,
+ * cplkavg.cpp).  Only tests/, __graft_entry__.smoke() and bench.py's
+ * cpu_baseline leg may load this library -- as the checker, never as the
+ * product.  The product (our_first_climate_model_amd + librcm_hip.so) neither
+ * links nor loads it.
+ *
+ * Parity pinning (see oracle/README.md, DESIGN.md section "Oracle"):
+ *   - solar known answers and the t=0 rows from the reference's output.txt,
+ *   - the [probe] outputs of the unmodified reference recorded in
+ *     SURVEY.md section 8(c) (tests/golden/survey_probe.json),
+ *   - cplkavg.cpp known answers + the reference cplkavg.cpp compiled as-is
+ *     into oracle/_ref/ (it needs only libm),
+ *   - the reference ascii.cpp compiled as-is into oracle/_ref/.
+ * main.cpp / repwvl_thermal.cpp need <netcdf> (netcdf-cxx4), absent from this
+ * image: unbuildable here, so that part is pinned by the recorded outputs.
+ *
+ * Conventions: layer index 0 = top of atmosphere; all arrays row-major;
+ * everything double except `time` (float, main.cpp:359).
+ */
+#ifndef RCM_ORACLE_H
+#define RCM_ORACLE_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ORC_NSPEC_REPWVL 9 /* H2O,CO2,O3,N2O,CO,CH4,O2,HNO3,N2  (repwvl_thermal.cpp:102-110) */
+#define ORC_NSPEC_LBL 5    /* CO2,H2O,O3,CH4,N2O                (lbl.arts/README:5)           */
+
+#define ORC_MODE_REPWVL 0
+#define ORC_MODE_LBL 1
+
+/* ---- small physics, one function per reference function ---- */
+
+/* main.cpp:214-264.  out = {r_dir, s_dir, t_dir, r, t, r_total, solar_irr} */
+void orc_solar_setup(double tau_s, double mu_s, int doublings, double g_asym, double albedo,
+                     double daytime, double E_0, double out[7]);
+/* the reference's compiled-in values: main.cpp:86-91 */
+void orc_default_solar(double out[7]);
+
+/* main.cpp:197-204 */
+double orc_planck_mono(double wvl_nm, double weight, double T);
+/* cplkavg.cpp:124-243.  Error (reference: exit(1)) -> returns NaN and bumps orc_cplkavg_errors(). */
+double orc_cplkavg(double wvllo, double wvlhi, double t);
+int orc_cplkavg_errors(void);
+/* main.cpp:277-279 */
+double orc_magnus(double T);
+
+/* repwvl_thermal.cpp:19-45 */
+int orc_lower_pos(const double *grid, int n, double x);
+
+/* repwvl_thermal.cpp:49-262 on a flattened table.  vmr = [9][nlayer] in read_tau argument
+ * order, absolute mixing ratios, top layer first.  tau out = [n_wvl][nlayer]. */
+void orc_read_tau(int n_tpert, int n_species, int n_wvl, int n_p, const double *p_grid,
+                  const double *t_ref, const double *t_pert, const double *xsec, int nlevel,
+                  const double *plevel_hPa, const double *Tlayer, const double *vmr, double *tau);
+
+/* lbl composition (build decision): tau[b][l] = sum_s scale[s][l] * tab_s[b][l],
+ * bands b = 0..n_nodes-2 take the optical depth of node b. tabs[s] = [n_nodes][nlayer]. */
+void orc_lbl_tau(int n_nodes, int nlayer, const double *const tabs[ORC_NSPEC_LBL],
+                 const double *scale /*[5][nlayer]*/, double *tau /*[n_nodes-1][nlayer]*/);
+
+/* main.cpp:266-274 */
+void orc_cloud_into_tau(double *tau, int nwvl, int nlayer, int cloud_layer, double cloud_tau);
+
+/* main.cpp:320-344 (+186-212, 291-318).  planck_mode 0: monochromatic*weight (main.cpp:186),
+ * wvl/weight have nspec entries.  planck_mode 1: band integral cplkavg(wvl[b], wvl[b+1], T),
+ * wvl has nspec+1 entries, weight ignored.  E_down/E_up [nlayer+1], dE [nlayer]. */
+void orc_radiative_transfer(int nspec, int nlayer, int nangle, const double *tau,
+                            const double *wvl, const double *weight, int planck_mode,
+                            const double *Tlayer, double T_surface, double solar_irr,
+                            double *E_down, double *E_up, double *dE);
+
+/* main.cpp:156-162 */
+double orc_calculate_timestep(double dp, const double *dE, int nlayer);
+/* main.cpp:164-176 */
+void orc_thermodynamics(double *Tlayer, int nlayer, double dp, const double *dE, double timestep,
+                        double *T_surface, const double *conv);
+/* main.cpp:536-540 */
+void orc_convective_adjustment(double *Tlayer, double *theta, const double *conv, int nlayer);
+/* main.cpp:281-289 */
+void orc_water_vapor_feedback(const double *Tlayer, const double *rel_hum, const double *player,
+                              double *h2o_vmr, int nlayer);
+
+/* ---- atmosphere file + column initialisation: main.cpp:396-485 ---- */
+
+/* Parses an .atm file the way main.cpp:396-430 does (4 header lines, whitespace columns).
+ * cols out = [9][nlevel_max]; 6-column files (fpda.lbl.atm) get CO2/CH4/N2O = 400/1.7/0.315
+ * (lbl.arts/README:14-17).  Returns number of levels read, <0 on error. */
+int orc_atm_load(const char *path, int nlevel_max, double *cols, int *ncols_found);
+
+/* main.cpp:439-485 for one column.  All outputs are nlayer long except noted.
+ * vmr9 = [9][nlayer] in read_tau order (absolute).  rel_hum built from LEVEL p/T and LAYER
+ * VMR exactly as main.cpp:467-468.  co2_factor as main.cpp:452; rh_scale multiplies the
+ * initial H2O VMR (1 = reference). */
+void orc_column_init(int nlevel, const double *atm_cols /*[9][nlevel]*/, double co2_factor,
+                     double rh_scale, double *plevel, double *player, double *Tlayer,
+                     double *conv, double *vmr9, double *rel_hum);
+
+/* ---- table blob ---- */
+int orc_rtab_load(const char *path, long long dims[4], double **blob); /* caller frees *blob */
+void orc_free(void *p);
+
+/* ---- ensemble handle: the same shape as the rcm_* C ABI (include/rcm.h) ---- */
+typedef struct orc_ensemble orc_ensemble;
+
+int orc_create(int ncol, int nlayer, int nangle, orc_ensemble **out);
+int orc_destroy(orc_ensemble *h);
+int orc_set_grid(orc_ensemble *h, const double *plevel_hPa);
+int orc_set_forcing(orc_ensemble *h, double solar_irr, int cloud_layer, double cloud_tau);
+int orc_set_repwvl_tables(orc_ensemble *h, int n_tpert, int n_species, int n_wvl, int n_p,
+                          const double *p_grid, const double *t_ref, const double *t_pert,
+                          const double *wvl, const double *weight, const double *xsec);
+int orc_set_lbl_tables(orc_ensemble *h, int n_nodes, const double *wvl,
+                       const double *const tabs[ORC_NSPEC_LBL], const double *h2o_ref);
+int orc_set_columns(orc_ensemble *h, const double *Tlayer0, const double *T_surface0,
+                    const double *gas, const double *rel_hum);
+int orc_set_threads(orc_ensemble *h, int nthreads);
+int orc_step(orc_ensemble *h, int nsteps);
+int orc_get_state(orc_ensemble *h, double *Tlayer, double *T_surface, float *time_h,
+                  double *timestep);
+int orc_get_fluxes(orc_ensemble *h, double *E_down, double *E_up, double *dE);
+int orc_get_profile(orc_ensemble *h, int col, double *Tlayer_adj, double *theta, float *time_h);
+int orc_get_tau(orc_ensemble *h, int col, double *tau);
+int orc_get_gas(orc_ensemble *h, double *gas);
+int orc_nspectral(orc_ensemble *h);
+int orc_threads_used(orc_ensemble *h);
+
+#ifdef __cplusplus
+}
+#endif
+#endif
