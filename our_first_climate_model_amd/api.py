@@ -1,0 +1,297 @@
+"""ctypes binding of librcm_hip.so -- one thin method per C-ABI entry point (include/rcm.h)."""
+import ctypes as C
+import os
+
+import numpy as np
+
+PKG = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(PKG, "librcm_hip.so")
+
+_dp = C.POINTER(C.c_double)
+_fp = C.POINTER(C.c_float)
+_ip = C.POINTER(C.c_int)
+
+NSPEC_REPWVL = 9
+NSPEC_LBL = 5
+
+_lib = None
+
+
+class RcmError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f"rcm error {code}: {msg}")
+        self.code = code
+
+
+def _p(a):
+    return None if a is None else a.ctypes.data_as(_dp)
+
+
+def _f64(a, shape=None, name="array"):
+    a = np.ascontiguousarray(a, dtype=np.float64)
+    if shape is not None and a.shape != tuple(shape):
+        raise ValueError(f"{name}: expected shape {tuple(shape)}, got {a.shape}")
+    return a
+
+
+def lib():
+    """Loads the HIP library; fails loudly when it has not been built (no fallback)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    # One HIP runtime per process: PyTorch ships its own libamdhip64.so.7 / libhsa-runtime64; if this
+    # library were loaded first it would pull /opt/rocm's copy in and the second runtime to initialise
+    # finds no device (observed on the MI355X box).  Importing torch first makes the loader resolve our
+    # DT_NEEDED libamdhip64.so.7 to the copy torch already mapped.  Without torch (C++ driver) the
+    # system runtime is the only one and is used as is.
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(f"{LIB_PATH} is missing: build it with `python -m our_first_climate_model_amd.build` "
+                          "(hipcc --offload-arch=gfx950). There is no CPU fallback.")
+    L = C.CDLL(LIB_PATH)
+    vp = C.c_void_p
+    L.rcm_abi_version.restype = C.c_int
+    L.rcm_last_error.restype = C.c_char_p
+    L.rcm_create.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, vp, C.POINTER(vp)]
+    L.rcm_destroy.argtypes = [vp]
+    L.rcm_set_grid.argtypes = [vp, _dp]
+    L.rcm_set_forcing.argtypes = [vp, C.c_double, C.c_int, C.c_double]
+    L.rcm_set_repwvl_tables.argtypes = [vp] + [C.c_int] * 4 + [_dp] * 6
+    L.rcm_set_lbl_tables.argtypes = [vp, C.c_int, _dp, C.POINTER(_dp), _dp]
+    L.rcm_set_columns.argtypes = [vp] + [_dp] * 4
+    L.rcm_step.argtypes = [vp, C.c_int]
+    L.rcm_sync.argtypes = [vp]
+    L.rcm_get_state.argtypes = [vp, _dp, _dp, _fp, _dp]
+    L.rcm_get_fluxes.argtypes = [vp, _dp, _dp, _dp]
+    L.rcm_get_profile.argtypes = [vp, C.c_int, _dp, _dp, _fp]
+    L.rcm_get_tau.argtypes = [vp, C.c_int, _dp]
+    L.rcm_get_gas.argtypes = [vp, _dp]
+    L.rcm_nspectral.argtypes = [vp]
+    L.rcm_pack_state.argtypes = [vp, vp]
+    L.rcm_set_spectral_chunks.argtypes = [vp, C.c_int]
+    L.rcm_get_spectral_chunks.argtypes = [vp]
+    L.rcm_set_rt_timing.argtypes = [vp, C.c_int]
+    L.rcm_get_rt_timing.argtypes = [vp, _dp, _ip]
+    L.rcm_atm_load.argtypes = [C.c_char_p, C.c_int, _dp, _ip, _ip]
+    L.rcm_column_init.argtypes = [C.c_int, _dp, C.c_double, C.c_double] + [_dp] * 6
+    L.rcm_solar_setup.argtypes = [C.c_double, C.c_double, C.c_int, C.c_double, C.c_double, C.c_double,
+                                  C.c_double, _dp]
+    L.rcm_default_solar.argtypes = [_dp]
+    L.rcm_ascii_file2xy2D.argtypes = [C.c_char_p, _ip, _ip, C.POINTER(_dp), C.POINTER(_dp)]
+    L.rcm_rtab_load.argtypes = [C.c_char_p, C.POINTER(C.c_longlong), C.POINTER(_dp)]
+    L.rcm_free.argtypes = [vp]
+    L.rcm_free.restype = None
+    L.rcm_write_banner.argtypes = [vp, C.c_double, C.c_double, _dp]
+    L.rcm_write_profile.argtypes = [vp, C.c_int, _dp, _dp, _dp, C.c_float]
+    _lib = L
+    return L
+
+
+def _ck(rc):
+    if rc != 0:
+        raise RcmError(rc, lib().rcm_last_error().decode(errors="replace"))
+
+
+# ------------------------------------------------------------------------------------------------
+# host-side pieces of the reference driver
+# ------------------------------------------------------------------------------------------------
+def atm_load(path, nlevel_max=21):
+    """main.cpp:396-430.  Returns (cols[9][nlevel], ncols_found)."""
+    cols = np.zeros((9, nlevel_max))
+    n, nc = C.c_int(0), C.c_int(0)
+    _ck(lib().rcm_atm_load(os.fsencode(path), nlevel_max, _p(cols), C.byref(n), C.byref(nc)))
+    return cols[:, :n.value].copy(), nc.value
+
+
+def column_init(atm_cols, co2_factor=1.0, rh_scale=1.0):
+    """main.cpp:439-485 for one column."""
+    a = _f64(atm_cols)
+    nlevel = a.shape[1]
+    nl = nlevel - 1
+    out = dict(plevel=np.zeros(nlevel), player=np.zeros(nl), Tlayer=np.zeros(nl), conv=np.zeros(nl),
+               vmr9=np.zeros((9, nl)), rel_hum=np.zeros(nl))
+    _ck(lib().rcm_column_init(nlevel, _p(a), co2_factor, rh_scale, _p(out["plevel"]), _p(out["player"]),
+                              _p(out["Tlayer"]), _p(out["conv"]), _p(out["vmr9"]), _p(out["rel_hum"])))
+    return out
+
+
+def solar_setup(tau_s, mu_s, doublings=20, g_asym=0.85, albedo=0.12, daytime=0.5, E_0=1361.0):
+    """main.cpp:214-264 -> dict(r_dir, s_dir, t_dir, r, t, r_total, solar_irr)."""
+    out = np.zeros(7)
+    _ck(lib().rcm_solar_setup(tau_s, mu_s, doublings, g_asym, albedo, daytime, E_0, _p(out)))
+    return dict(zip(("r_dir", "s_dir", "t_dir", "r", "t", "r_total", "solar_irr"), out.tolist()))
+
+
+def default_solar():
+    out = np.zeros(7)
+    _ck(lib().rcm_default_solar(_p(out)))
+    return dict(zip(("r_dir", "s_dir", "t_dir", "r", "t", "r_total", "solar_irr"), out.tolist()))
+
+
+def ascii_file2xy2D(path):
+    """ASCII_file2xy2D (lbl.arts/ascii.cpp:1631-1691).  Returns (status, x[nx], y[nx][ny])."""
+    nx, ny = C.c_int(0), C.c_int(0)
+    x, y = _dp(), _dp()
+    st = lib().rcm_ascii_file2xy2D(os.fsencode(path), C.byref(nx), C.byref(ny), C.byref(x), C.byref(y))
+    if st != 0:
+        return st, None, None
+    xs = np.ctypeslib.as_array(x, (nx.value,)).copy()
+    ys = np.ctypeslib.as_array(y, (nx.value, max(ny.value, 1))).copy()[:, :ny.value]
+    lib().rcm_free(x)
+    lib().rcm_free(y)
+    return 0, xs, ys
+
+
+def read_rtab(path):
+    """The datasets of a flattened Reduced*Forcing.nc (tools/flatten_repwvl.py) via rcm_rtab_load."""
+    dims = (C.c_longlong * 4)()
+    blob = _dp()
+    _ck(lib().rcm_rtab_load(os.fsencode(path), dims, C.byref(blob)))
+    nt, ns, nw, n_p = (int(v) for v in dims)
+    n = n_p + n_p + nt + ns * n_p + nw + nw + nt * ns * nw * n_p
+    a = np.ctypeslib.as_array(blob, (n,)).copy()
+    lib().rcm_free(blob)
+    o = 0
+
+    def take(k, shape=None):
+        nonlocal o
+        v = a[o:o + k].copy()
+        o += k
+        return v if shape is None else v.reshape(shape)
+
+    t = dict(n_tpert=nt, n_species=ns, n_wvl=nw, n_p=n_p)
+    t["p_grid"], t["t_ref"], t["t_pert"] = take(n_p), take(n_p), take(nt)
+    t["vmrs_ref"] = take(ns * n_p, (ns, n_p))
+    t["wvl"], t["weight"] = take(nw), take(nw)
+    t["xsec"] = take(nt * ns * nw * n_p, (nt, ns, nw, n_p))
+    return t
+
+
+# ------------------------------------------------------------------------------------------------
+# the ensemble handle
+# ------------------------------------------------------------------------------------------------
+class Ensemble:
+    """An ensemble of independent columns on one MI355X (rcm_ensemble, include/rcm.h)."""
+
+    def __init__(self, ncol, nlayer=20, nangle=30, device=0, stream=None):
+        self.ncol, self.nlayer, self.nangle, self.device = ncol, nlayer, nangle, device
+        self.ngas = None
+        self.h = C.c_void_p()
+        _ck(lib().rcm_create(ncol, nlayer, nangle, device, C.c_void_p(stream) if stream else None,
+                             C.byref(self.h)))
+
+    def close(self):
+        if getattr(self, "h", None):
+            lib().rcm_destroy(self.h)
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    def set_grid(self, plevel):
+        _ck(lib().rcm_set_grid(self.h, _p(_f64(plevel, (self.nlayer + 1,), "plevel"))))
+
+    def set_forcing(self, solar_irr, cloud_layer=17, cloud_tau=1.0):
+        _ck(lib().rcm_set_forcing(self.h, solar_irr, cloud_layer, cloud_tau))
+
+    def set_repwvl_tables(self, t):
+        arrs = [_f64(t[k]) for k in ("p_grid", "t_ref", "t_pert", "wvl", "weight", "xsec")]
+        _ck(lib().rcm_set_repwvl_tables(self.h, t["n_tpert"], t["n_species"], t["n_wvl"], t["n_p"],
+                                        *[_p(a) for a in arrs]))
+        self.ngas = NSPEC_REPWVL
+
+    def set_lbl_tables(self, wvl, tabs, h2o_ref):
+        wvl = _f64(wvl)
+        tabs = [_f64(x, (wvl.size, self.nlayer), "lbl table") for x in tabs]
+        if len(tabs) != NSPEC_LBL:
+            raise ValueError("need 5 species tables (CO2, H2O, O3, CH4, N2O)")
+        h2o_ref = _f64(h2o_ref, (self.nlayer,), "h2o_ref")
+        arr = (_dp * NSPEC_LBL)(*[_p(x) for x in tabs])
+        _ck(lib().rcm_set_lbl_tables(self.h, wvl.size, _p(wvl), arr, _p(h2o_ref)))
+        self.ngas = NSPEC_LBL
+
+    def set_columns(self, Tlayer0, T_surface0, gas, rel_hum):
+        if self.ngas is None:
+            raise RcmError(-2, "set the spectral tables before the columns")
+        T = _f64(Tlayer0, (self.ncol, self.nlayer), "Tlayer0")
+        Ts = _f64(T_surface0, (self.ncol,), "T_surface0")
+        g = _f64(gas, (self.ncol, self.ngas, self.nlayer), "gas")
+        rh = _f64(rel_hum, (self.ncol, self.nlayer), "rel_hum")
+        _ck(lib().rcm_set_columns(self.h, _p(T), _p(Ts), _p(g), _p(rh)))
+
+    def step(self, n=1):
+        _ck(lib().rcm_step(self.h, n))
+
+    def sync(self):
+        _ck(lib().rcm_sync(self.h))
+
+    def get_state(self):
+        T = np.zeros((self.ncol, self.nlayer))
+        Ts = np.zeros(self.ncol)
+        tm = np.zeros(self.ncol, dtype=np.float32)
+        dt = np.zeros(self.ncol)
+        _ck(lib().rcm_get_state(self.h, _p(T), _p(Ts), tm.ctypes.data_as(_fp), _p(dt)))
+        return dict(Tlayer=T, T_surface=Ts, time_h=tm, timestep=dt)
+
+    def get_fluxes(self):
+        Ed = np.zeros((self.ncol, self.nlayer + 1))
+        Eu = np.zeros((self.ncol, self.nlayer + 1))
+        dE = np.zeros((self.ncol, self.nlayer))
+        _ck(lib().rcm_get_fluxes(self.h, _p(Ed), _p(Eu), _p(dE)))
+        return dict(E_down=Ed, E_up=Eu, dE=dE)
+
+    def get_profile(self, col=0):
+        T = np.zeros(self.nlayer)
+        th = np.zeros(self.nlayer)
+        tm = C.c_float(0)
+        _ck(lib().rcm_get_profile(self.h, col, _p(T), _p(th), C.byref(tm)))
+        return T, th, tm.value
+
+    def nspectral(self):
+        n = lib().rcm_nspectral(self.h)
+        if n < 0:
+            _ck(n)
+        return n
+
+    def get_tau(self, col=0):
+        tau = np.zeros((self.nspectral(), self.nlayer))
+        _ck(lib().rcm_get_tau(self.h, col, _p(tau)))
+        return tau
+
+    def get_gas(self):
+        g = np.zeros((self.ncol, self.ngas, self.nlayer))
+        _ck(lib().rcm_get_gas(self.h, _p(g)))
+        return g
+
+    def pack_state(self, dev_ptr):
+        """Writes [ncol][nlayer+1] (Tlayer, T_surface) to a DEVICE pointer (e.g. tensor.data_ptr())."""
+        _ck(lib().rcm_pack_state(self.h, C.c_void_p(dev_ptr)))
+
+    def set_spectral_chunks(self, n):
+        _ck(lib().rcm_set_spectral_chunks(self.h, n))
+
+    def get_spectral_chunks(self):
+        n = lib().rcm_get_spectral_chunks(self.h)
+        if n < 0:
+            _ck(n)
+        return n
+
+    def set_rt_timing(self, on=True):
+        _ck(lib().rcm_set_rt_timing(self.h, 1 if on else 0))
+
+    def get_rt_timing(self):
+        ms, n = C.c_double(0), C.c_int(0)
+        _ck(lib().rcm_get_rt_timing(self.h, C.byref(ms), C.byref(n)))
+        return ms.value, n.value

@@ -1,0 +1,44 @@
+"""Builds librcm_hip.so (HIP kernels + C ABI + host pieces) and the rcm_main driver, in-tree,
+for gfx950.  hipcc cross-compiles without a GPU.  Usage: python -m our_first_climate_model_amd.build"""
+import os
+import subprocess
+import sys
+
+PKG = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(PKG)
+CSRC = os.path.join(PKG, "csrc")
+LIB = os.path.join(PKG, "librcm_hip.so")
+MAIN = os.path.join(PKG, "rcm_main")
+HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+
+SOURCES = ["rcm_kernels.hip", "rcm_host.cpp"]
+HEADERS = ["rcm_device.hpp", "rcm_internal.hpp", "rcm_exp_coef.hpp"]
+
+
+def _newer(target, deps):
+    if not os.path.exists(target):
+        return True
+    t = os.path.getmtime(target)
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def build(force=False, verbose=False):
+    srcs = [os.path.join(CSRC, s) for s in SOURCES]
+    deps = srcs + [os.path.join(CSRC, h) for h in HEADERS] + [os.path.join(ROOT, "include", "rcm.h")]
+    common = ["-O3", "-std=c++17", "-fPIC", "--offload-arch=gfx950", "-I" + os.path.join(ROOT, "include"),
+              "-I" + CSRC, "-Wall", "-Wno-unused-function"]
+    if force or _newer(LIB, deps):
+        cmd = [HIPCC] + common + ["-shared", "-o", LIB] + srcs
+        if verbose:
+            cmd.insert(1, "-Rpass-analysis=kernel-resource-usage")
+        subprocess.run(cmd, check=True)
+    main_src = os.path.join(CSRC, "rcm_main.cpp")
+    if os.path.exists(main_src) and (force or _newer(MAIN, [main_src, LIB])):
+        subprocess.run(["g++", "-O2", "-std=c++17", "-I" + os.path.join(ROOT, "include"), "-o", MAIN, main_src,
+                        "-L" + PKG, "-lrcm_hip", "-Wl,-rpath,$ORIGIN"], check=True)
+    return LIB
+
+
+if __name__ == "__main__":
+    build(force="--force" in sys.argv, verbose="-v" in sys.argv)
+    print(LIB)

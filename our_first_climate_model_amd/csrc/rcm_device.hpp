@@ -1,0 +1,156 @@
+// rcm_device.hpp -- device-side physics for the gfx950 kernels.
+//
+// Every function names the reference function it restates.  fp64 throughout; no fast-math.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "rcm_exp_coef.hpp"
+
+namespace rcm {
+
+// ---------------------------------------------------------------------------------------------
+// exp(x) for the transmission t = exp(-tau/mu) (main.cpp:209), x <= 0 in normal use.
+//
+// EXPV 0: the ROCm device library's exp (reference-grade, ~1 ulp).
+// EXPV 1: shared-nothing ALU version: k = rint(x*log2e) by the 1.5*2^52 trick (the integer
+//         falls out of the low mantissa word for free), r = x - k*ln2 in two FMAs, degree-10
+//         near-minimax polynomial (max rel err 2.9e-16 + rounding), 2^k applied by an integer
+//         add into the exponent field.  x is clamped to [-708, 708] first so the result
+//         is a normal number and the exponent add cannot wrap: exp(-708) = 3e-308 stands in for
+//         everything smaller, which is indistinguishable in 1 - t and t*(L - B).
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ double exp_poly10(double x) {
+  constexpr double kLog2e = 0x1.71547652b82fep+0;
+  constexpr double kLn2Hi = 0x1.62e42fefa39efp-1;   // ln2 rounded to double
+  constexpr double kLn2Lo = 0x1.abc9e3b39803fp-56;  // ln2 - kLn2Hi
+  constexpr double kMagic = 0x1.8p+52;              // 1.5 * 2^52
+  x = fmax(x, -708.0);
+  x = fmin(x, 708.0);
+  const double z = fma(x, kLog2e, kMagic);
+  const double kf = z - kMagic;
+  double r = fma(kf, -kLn2Hi, x);
+  r = fma(kf, -kLn2Lo, r);
+  double p = kExpPoly10[10];
+#pragma unroll
+  for (int i = 9; i >= 0; --i) p = fma(p, r, kExpPoly10[i]);
+  // 2^k: add k to the biased exponent (bits 52..62 = bits 20..30 of the high word)
+  const int k = __double2loint(z);
+  const int hi = __double2hiint(p) + (k << 20);
+  return __hiloint2double(hi, __double2loint(p));
+}
+
+template <int EXPV>
+__device__ __forceinline__ double exp_t(double x) {
+  if constexpr (EXPV == 0)
+    return exp(x);
+  else
+    return exp_poly10(x);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Monochromatic Planck radiance times spectral weight: main.cpp:186-204.
+//   weight*2*h*c^2 / (lambda^5 * (exp(h*c/(lambda*kB*T)) - 1)) / 1e9
+// pnum = ((weight*2)*h)*pow(c,2) and lam5 = pow(lambda,5), lkb = lambda*kB are formed on the
+// host once per wavelength in the reference's operation order (lambda in metres).
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ double planck_mono(double pnum, double lam5, double lkb, double T) {
+  constexpr double kHC = 6.62607e-34 * 299792458.0;  // h*c, main.cpp:70-71 (one rounding, as h*c there)
+  return pnum / (lam5 * (exp(kHC / (lkb * T)) - 1)) / 1e9;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Band-integrated Planck function: cplkavg.cpp:124-243 (libRadtran c_planck_func1).
+// Takes the wavenumber bounds (cplkavg.cpp:141-142 done by the caller, once per band) and
+// tpre = sigdpi * pow(t,4) (formed once per column-layer).  Same branches as the reference:
+// Simpson iteration to 1e-6 when the bounds are close (:155-182), else power / exponential
+// series (:187-237).  The reference's exit(1) on bad input (:144-146) cannot happen on the
+// device: the host rejects non-increasing wavelengths and negative temperatures give NaN.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ double plkf(double x) { return x * x * x / (exp(x) - 1.); }  // :109-113
+
+__device__ inline double cplkavg_dev(double wnumlo, double wnumhi, double t, double tpre) {
+  constexpr double A1 = 1. / 3., A2 = -1. / 8., A3 = 1. / 60., A4 = -1. / 5040., A5 = 1. / 272160.,
+                   A6 = -1. / 13305600.;
+  constexpr double C2 = 1.438786, VCUT = 1.5;
+  constexpr double kVmax = 0x1.62e42fefa39efp+9;                  // log(DBL_MAX), :133
+  constexpr double kConc = 15. / (M_PI * M_PI * M_PI * M_PI);     // :135 (pow(M_PI,4.) differs by <= 1 ulp)
+  constexpr double kEps = 2.2204460492503131e-16;                 // DBL_EPSILON
+  if (t < 1.e-4) return 0.;                                       // :148
+  const double v0 = C2 * wnumlo / t, v1 = C2 * wnumhi / t;        // :152-153
+  if (v0 > kEps && v1 < kVmax && (wnumhi - wnumlo) / wnumhi < 1.e-2) {  // :155
+    const double hh = v1 - v0;
+    double oldval = 0., val = 0.;
+    const double val0 = plkf(v0) + plkf(v1);
+    for (int n = 1; n <= 10; n++) {                               // :163
+      const double del = hh / (2 * n);
+      val = val0;
+      for (int k = 1; k <= 2 * n - 1; k++)
+        val += (double)(2 * (1 + k % 2)) * plkf(v0 + (double)k * del);
+      val *= del * A1;
+      if (fabs((val - oldval) / val) <= 1.e-6) break;             // :170
+      oldval = val;
+    }
+    return tpre * kConc * val;                                    // :181
+  }
+  const double vcp[7] = {10.25, 5.7, 3.9, 2.9, 2.3, 1.9, 0.0};
+  double d[2] = {0., 0.}, p[2] = {0., 0.};
+  int smallv = 0;
+  const double v[2] = {v0, v1};
+#pragma unroll
+  for (int i = 0; i < 2; i++) {                                   // :188
+    const double vi = v[i];
+    if (vi < VCUT) {
+      smallv++;
+      const double vsq = vi * vi;
+      p[i] = kConc * vsq * vi * (A1 + vi * (A2 + vi * (A3 + vsq * (A4 + vsq * (A5 + vsq * A6)))));
+    } else {
+      int mmax = 1;
+      while (vi < vcp[mmax - 1]) mmax++;                          // :203
+      const double ex = exp(-vi);
+      double exm = 1., di = 0.;
+      for (int m = 1; m <= mmax; m++) {
+        const double mv = (double)m * vi;
+        exm = ex * exm;
+        di += exm * (6. + mv * (6. + mv * (3. + mv))) / (double)(m * m * m * m);
+      }
+      d[i] = di * kConc;
+    }
+  }
+  double ans;
+  if (smallv == 2)
+    ans = p[1] - p[0];
+  else if (smallv == 1)
+    ans = 1. - p[0] - d[1];
+  else
+    ans = d[0] - d[1];
+  return ans * tpre;                                              // :237
+}
+
+// Magnus saturation vapour pressure [hPa]: main.cpp:277-279
+__device__ __forceinline__ double magnus_dev(double T) {
+  return 6.1094 * exp(17.625 * (T - 273.15) / (T - 273.15 + 243.04));
+}
+
+// LowerPos on a small grid: repwvl_thermal.cpp:19-45 (first sign change of grid[i]-x, clamped).
+__device__ __forceinline__ int sgn_dev(double v) { return (0.0 < v) - (v < 0.0); }
+
+template <typename F>
+__device__ __forceinline__ int lower_pos_dev(F grid, int n, double x) {
+  int sign = sgn_dev(grid(0) - x);
+  for (int p = 1; p != n; ++p) {
+    const double delta = grid(p) - x;
+    if (sign != sgn_dev(delta)) return p - 1;
+    if (p == n - 1) return p - 1;
+    sign = sgn_dev(delta);
+  }
+  return 0;
+}
+
+// 64-lane butterfly sum; every lane ends with the total (fixed order: deterministic).
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
+  return v;
+}
+
+}  // namespace rcm

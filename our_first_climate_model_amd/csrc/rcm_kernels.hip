@@ -1,0 +1,988 @@
+// rcm_kernels.hip -- gfx950 (CDNA4) kernels of the radiative-convective column ensemble and the
+// C ABI that drives them (include/rcm.h).
+//
+// Mapping: one wavefront (64 lanes) per (column, spectral chunk); spectral points
+// on lanes; the column's level grid (temperatures, gas scalings, interpolation brackets) in
+// LDS, read as broadcasts; 41 flux accumulators per lane in VGPRs, reduced across the wave by
+// a butterfly at the end of the chunk; chunk partials summed in fixed order by the time-step
+// kernel.  fp64 everywhere.  No MFMA: there is no dense contraction on this path.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "rcm.h"
+#include "rcm_device.hpp"
+#include "rcm_internal.hpp"
+
+namespace rcm {
+
+constexpr int NL = 20;       // layers   (main.cpp:78); kernels are specialised for it
+constexpr int NLEV = NL + 1; // levels   (main.cpp:79)
+constexpr int PSTRIDE = 2 * NLEV;  // one partial record: E_down[21], E_up[21]
+constexpr int WPB = 4;       // waves per block = columns per block (one per SIMD)
+
+enum { MODE_NONE = -1, MODE_REPWVL = 0, MODE_LBL = 1 };
+
+// Everything a kernel needs, passed by value.
+struct Dev {
+  int ncol, nangle, mode, ngas;
+  int nspec;      // spectral points: n_wvl (repwvl) or bands = n_nodes-1 (lbl)
+  int nchunk;     // spectral chunks per column
+  int chunk_len;  // points per chunk (multiple of 64)
+  int cloud_layer;
+  double cloud_tau, solar_irr, dp, sigdpi;
+  const double *player, *conv, *ang;  // ang = [inv_mu[nangle], cw[nangle]]
+  double *T, *Ttau, *Tsfc, *dt, *gas, *E_down, *E_up, *dE, *partial;
+  const double *rel_hum;
+  float *time_h;
+  // lbl: tab[s][l][ld] (band fastest), wvl[n_nodes], h2o_ref[NL]
+  const double *lbl_tab, *lbl_wvl, *h2o_ref;
+  long lbl_ld;
+  // repwvl: xsec[t][s][p][w] (wavelength fastest)
+  const double *xsec, *t_ref, *t_pert, *delP, *numDens, *pnum, *lam5, *lkb;
+  const int *ip;
+  int n_tpert, n_species, n_p, n_wvl;
+  unsigned species_mask;
+};
+
+// ---------------------------------------------------------------------------------------------
+// Schwarzschild sweep for one angle (main.cpp:297-315) on the lane's spectral point.
+// t[l] = exp(-tau_l/mu).  The reference's L = (1-alpha)*L + alpha*B with alpha = 1-t is
+// evaluated as B + t*(L-B).
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ void sweep(const double (&t)[NL], const double (&B)[NL], double Bs,
+                                      double cw, double (&Ed)[NLEV], double (&Eu)[NLEV]) {
+  double L = 0.0;  // main.cpp:300
+#pragma unroll
+  for (int l = 0; l < NL; ++l) {  // main.cpp:306-309
+    L = fma(t[l], L - B[l], B[l]);
+    Ed[l + 1] = fma(cw, L, Ed[l + 1]);
+  }
+  double Lu = Bs;                 // main.cpp:301
+  Eu[NL] = fma(cw, Lu, Eu[NL]);   // main.cpp:302
+#pragma unroll
+  for (int l = NL - 1; l >= 0; --l) {  // main.cpp:311-314
+    Lu = fma(t[l], Lu - B[l], B[l]);
+    Eu[l] = fma(cw, Lu, Eu[l]);
+  }
+}
+
+// All angles for one spectral point.  CUBE: mu_i = (2i+1)/(2 nangle), so the transmission at
+// odd n = 2i+1 obeys t_{n/3} = t_n^3; only the angles with 3n > 2 nangle - 1 need an exp, the
+// rest follow by two multiplications per layer (20 instead of 30 exp per layer at nangle 30).
+template <int EXPV, int CUBE>
+__device__ __forceinline__ void all_angles(const Dev &d, const double (&tau)[NL],
+                                           const double (&B)[NL], double Bs, double (&Ed)[NLEV],
+                                           double (&Eu)[NLEV]) {
+  const int na = d.nangle;
+  if constexpr (!CUBE) {
+    for (int i = 0; i < na; ++i) {
+      const double inv_mu = d.ang[i], cw = d.ang[na + i];
+      double t[NL];
+#pragma unroll
+      for (int l = 0; l < NL; ++l) t[l] = exp_t<EXPV>(-tau[l] * inv_mu);  // main.cpp:209
+      sweep(t, B, Bs, cw, Ed, Eu);
+    }
+  } else {
+    const int N = 2 * na - 1;
+    for (int n = N; 3 * n > N; n -= 2) {
+      const double inv_mu = d.ang[(n - 1) >> 1];
+      double t[NL];
+#pragma unroll
+      for (int l = 0; l < NL; ++l) t[l] = exp_t<EXPV>(-tau[l] * inv_mu);
+      int m = n;
+      for (;;) {
+        sweep(t, B, Bs, d.ang[na + ((m - 1) >> 1)], Ed, Eu);
+        if (m % 3 != 0) break;
+        m /= 3;
+#pragma unroll
+        for (int l = 0; l < NL; ++l) t[l] = t[l] * t[l] * t[l];
+      }
+    }
+  }
+}
+
+// Butterfly-reduce the accumulators of a wave and let lane 0 store the partial record.
+__device__ __forceinline__ void store_partial(const Dev &d, int col, int chunk, int lane, bool valid,
+                                              double (&Ed)[NLEV], double (&Eu)[NLEV]) {
+  double *out = d.partial + ((size_t)col * d.nchunk + chunk) * PSTRIDE;
+#pragma unroll
+  for (int j = 0; j < NLEV; ++j) {
+    const double a = wave_sum(Ed[j]);
+    const double b = wave_sum(Eu[j]);
+    if (lane == 0 && valid) {
+      out[j] = a;
+      out[NLEV + j] = b;
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// lbl optical depth of band b (DESIGN.md "lbl composition"; format lbl.arts/README:5-17):
+// tau_l = sum_s scale[s][l] * tab_s[b][l] (+ grey cloud, main.cpp:266-274).
+// sc = the column's [5][NL] multipliers in LDS.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ double lbl_tau_layer(const Dev &d, const double *sc, long b, int l) {
+  double acc = 0.0;
+#pragma unroll
+  for (int s = 0; s < RCM_NSPEC_LBL; ++s)
+    acc = fma(sc[s * NL + l], d.lbl_tab[(size_t)(s * NL + l) * d.lbl_ld + b], acc);
+  if (l == d.cloud_layer) acc += d.cloud_tau;
+  return acc;
+}
+
+// ---------------------------------------------------------------------------------------------
+// repwvl optical depth at wavelength w: read_tau, repwvl_thermal.cpp:197-248.
+// Per column-layer (wave prologue, LDS): it = LowerPos(t_ref[ip]+t_pert, T) and delT (:229-239).
+// Per layer (host, once): ip = LowerPos(p_grid, midP), delP, numDens (:201-202, 226, 240).
+// ---------------------------------------------------------------------------------------------
+struct RepwvlLds {
+  double T[NL + 1];          // Tlayer, T_surface
+  double delT[NL];
+  double vmr[RCM_NSPEC_REPWVL * NL];
+  int it[NL];
+};
+
+__device__ __forceinline__ void repwvl_prologue(const Dev &d, int col, int lane, RepwvlLds &s) {
+  if (lane < NL) {
+    s.T[lane] = d.T[(size_t)col * NL + lane];
+    const double midT = d.Ttau[(size_t)col * NL + lane];  // :217 (prop_at_Lev == 0)
+    const int ip = d.ip[lane];
+    const double tr = d.t_ref[ip];
+    const double *tp = d.t_pert;
+    const int it = lower_pos_dev([&](int k) { return tr + tp[k]; }, d.n_tpert, midT);  // :229-232
+    const double t0 = tr + tp[it], t1 = tr + tp[it + 1];
+    s.it[lane] = it;
+    s.delT[lane] = (midT - t0) / (t1 - t0);  // :239
+  }
+  if (lane == NL) s.T[NL] = d.Tsfc[col];
+  for (int i = lane; i < d.ngas * NL; i += 64) s.vmr[i] = d.gas[(size_t)col * d.ngas * NL + i];
+}
+
+// One layer of read_tau's interpolation for the lane's wavelength (:210-246).
+__device__ __forceinline__ double repwvl_tau_layer(const Dev &d, const RepwvlLds &s, int w, int l) {
+  const size_t ld = d.n_wvl;
+  const int it = s.it[l], ip = d.ip[l];
+  const double delT = s.delT[l], delP = d.delP[l];
+  double acc = 0.0;
+#pragma unroll
+  for (int sp = 0; sp < RCM_NSPEC_REPWVL; ++sp) {
+    if (!((d.species_mask >> sp) & 1u)) continue;  // vmr == 0 everywhere: the term is +0
+    const double *x0 = d.xsec + (((size_t)it * d.n_species + sp) * d.n_p + ip) * ld + w;
+    const double *x1 = d.xsec + (((size_t)(it + 1) * d.n_species + sp) * d.n_p + ip) * ld + w;
+    const double c0 = x0[0];                      // :235
+    const double cT = x1[0] - c0;                 // :236
+    const double cP = x0[ld] - c0;                // :237
+    const double cPT = x1[ld] - cP - cT - c0;     // :238
+    const double xs = c0 + cT * delT + cP * delP + cPT * delT * delP;  // :241
+    acc += xs * s.vmr[sp * NL + l];               // :244
+  }
+  acc *= d.numDens[l];                            // :246
+  if (l == d.cloud_layer) acc += d.cloud_tau;     // main.cpp:266-274
+  return acc;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Thermal RT, lbl spectra: radiative_transfer (main.cpp:320-344) with the band Planck source
+// cplkavg (cplkavg.cpp:124-243) and optical depths assembled on the fly.
+// grid = nchunk * ceil(ncol/4) blocks of 4 waves; the 4 waves of a block (and neighbouring
+// blocks) work on the SAME spectral chunk of different columns, so a table tile is fetched
+// from HBM once and then served from L2 to every column.
+// ---------------------------------------------------------------------------------------------
+template <int EXPV, int CUBE>
+__global__ __launch_bounds__(64 * WPB, 2) void k_rt_lbl(Dev d) {
+  __shared__ double s_col[WPB][192];
+  __shared__ double s_stage[WPB][NLEV][64];  // per-lane scratch column, indexable at run time
+  const int lane = threadIdx.x & 63;
+  const int wib = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int ncg = (d.ncol + WPB - 1) / WPB;
+  const int chunk = blockIdx.x / ncg;
+  const int colraw = (blockIdx.x - chunk * ncg) * WPB + wib;
+  const bool valid = colraw < d.ncol;
+  const int col = valid ? colraw : d.ncol - 1;
+  double(*st)[64] = s_stage[wib];
+  // LDS: [0..19] Tlayer, [20] T_surface, [21..41] sigdpi*T^4, [48..147] gas multipliers [5][20]
+  double *sc = s_col[wib];
+  if (lane < NL) sc[lane] = d.T[(size_t)col * NL + lane];
+  if (lane == NL) sc[NL] = d.Tsfc[col];
+  for (int i = lane; i < RCM_NSPEC_LBL * NL; i += 64) sc[48 + i] = d.gas[(size_t)col * RCM_NSPEC_LBL * NL + i];
+  __syncthreads();
+  if (lane <= NL) sc[NLEV + lane] = d.sigdpi * pow(sc[lane], 4.0);  // cplkavg.cpp:181,237
+  __syncthreads();
+
+  double Ed[NLEV], Eu[NLEV];
+#pragma unroll
+  for (int j = 0; j < NLEV; ++j) Ed[j] = Eu[j] = 0.0;  // main.cpp:326-327
+
+  const long b0 = (long)chunk * d.chunk_len;
+  const long b1 = min(b0 + (long)d.chunk_len, (long)d.nspec);
+  for (long b = b0 + lane; b < b1; b += 64) {  // main.cpp:329, lanes over spectral points
+    double tau[NL], B[NL];
+#pragma unroll 4
+    for (int l = 0; l < NL; ++l) st[l][lane] = lbl_tau_layer(d, sc + 48, b, l);
+#pragma unroll
+    for (int l = 0; l < NL; ++l) tau[l] = st[l][lane];
+    const double wnumhi = 1.0E7 / d.lbl_wvl[b];      // cplkavg.cpp:141
+    const double wnumlo = 1.0E7 / d.lbl_wvl[b + 1];  // cplkavg.cpp:142
+#pragma unroll 1
+    for (int l = 0; l <= NL; ++l) st[l][lane] = cplkavg_dev(wnumlo, wnumhi, sc[l], sc[NLEV + l]);
+#pragma unroll
+    for (int l = 0; l < NL; ++l) B[l] = st[l][lane];
+    const double Bs = st[NL][lane];
+    all_angles<EXPV, CUBE>(d, tau, B, Bs, Ed, Eu);
+  }
+  store_partial(d, col, chunk, lane, valid, Ed, Eu);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Thermal RT, repwvl reduced-wavelength set: read_tau interpolation (repwvl_thermal.cpp:197-248)
+// fused with radiative_transfer (main.cpp:320-344, monochromatic Planck main.cpp:186-204).
+// tau never touches HBM.
+// ---------------------------------------------------------------------------------------------
+template <int EXPV, int CUBE>
+__global__ __launch_bounds__(64 * WPB, 2) void k_rt_repwvl(Dev d) {
+  __shared__ RepwvlLds s_col[WPB];
+  __shared__ double s_stage[WPB][NLEV][64];
+  const int lane = threadIdx.x & 63;
+  const int wib = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int ncg = (d.ncol + WPB - 1) / WPB;
+  const int chunk = blockIdx.x / ncg;
+  const int colraw = (blockIdx.x - chunk * ncg) * WPB + wib;
+  const bool valid = colraw < d.ncol;
+  const int col = valid ? colraw : d.ncol - 1;
+  RepwvlLds &s = s_col[wib];
+  double(*st)[64] = s_stage[wib];
+  repwvl_prologue(d, col, lane, s);
+  __syncthreads();
+
+  double Ed[NLEV], Eu[NLEV];
+#pragma unroll
+  for (int j = 0; j < NLEV; ++j) Ed[j] = Eu[j] = 0.0;
+
+  const int w0 = chunk * d.chunk_len;
+  const int w1 = min(w0 + d.chunk_len, d.nspec);
+  for (int w = w0 + lane; w < w1; w += 64) {
+    double tau[NL], B[NL];
+#pragma unroll 1
+    for (int l = 0; l < NL; ++l) st[l][lane] = repwvl_tau_layer(d, s, w, l);
+#pragma unroll
+    for (int l = 0; l < NL; ++l) tau[l] = st[l][lane];
+    const double pnum = d.pnum[w], lam5 = d.lam5[w], lkb = d.lkb[w];
+#pragma unroll 1
+    for (int l = 0; l <= NL; ++l) st[l][lane] = planck_mono(pnum, lam5, lkb, s.T[l]);  // main.cpp:331, :301
+#pragma unroll
+    for (int l = 0; l < NL; ++l) B[l] = st[l][lane];
+    const double Bs = st[NL][lane];
+    all_angles<EXPV, CUBE>(d, tau, B, Bs, Ed, Eu);
+  }
+  store_partial(d, col, chunk, lane, valid, Ed, Eu);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Convective adjustment: theta = T*conv, sort descending, T = theta/conv (main.cpp:123-139,
+// 536-540).  Odd-even transposition network on registers: static indices, no scratch.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ void adjust(const double *conv, double (&T)[NL], double (&th)[NL]) {
+#pragma unroll
+  for (int i = 0; i < NL; ++i) th[i] = T[i] * conv[i];
+#pragma unroll
+  for (int r = 0; r < NL; ++r) {
+#pragma unroll
+    for (int i = (r & 1); i + 1 < NL; i += 2) {
+      const double a = th[i], b = th[i + 1];
+      th[i] = fmax(a, b);
+      th[i + 1] = fmin(a, b);
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < NL; ++i) T[i] = th[i] / conv[i];
+}
+
+// One thread per column.  Start of loop iteration i (main.cpp:536-572) up to the optical-depth
+// inputs: adjustment, and for i != 0 the water-vapour feedback (main.cpp:281-289).
+__global__ void k_pre(Dev d, int first) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= d.ncol) return;
+  double T[NL], th[NL];
+#pragma unroll
+  for (int i = 0; i < NL; ++i) T[i] = d.T[(size_t)c * NL + i];
+  if (first) {  // main.cpp:500: the first optical depths come from the pre-adjustment profile
+#pragma unroll
+    for (int i = 0; i < NL; ++i) d.Ttau[(size_t)c * NL + i] = T[i];
+  }
+  adjust(d.conv, T, th);
+#pragma unroll
+  for (int i = 0; i < NL; ++i) d.T[(size_t)c * NL + i] = T[i];
+  if (!first) {
+    double *gas = d.gas + (size_t)c * d.ngas * NL;
+#pragma unroll
+    for (int i = 0; i < NL; ++i) {
+      d.Ttau[(size_t)c * NL + i] = T[i];
+      const double vmr = d.rel_hum[(size_t)c * NL + i] * magnus_dev(T[i]) / d.player[i];  // main.cpp:285-286
+      if (d.mode == MODE_REPWVL)
+        gas[0 * NL + i] = vmr;                 // H2O is read_tau's first species
+      else
+        gas[1 * NL + i] = vmr / d.h2o_ref[i];  // lbl: tau_H2O is linear in the mixing ratio
+    }
+  }
+}
+
+// One wave per column.  Sums the chunk partials in chunk order, then the tail of
+// radiative_transfer (main.cpp:337-341), calculate_timestep (:156-162), thermodynamics
+// (:164-176) and the time accumulation (:581).
+__global__ __launch_bounds__(64) void k_post(Dev d) {
+  __shared__ double s_E[PSTRIDE];
+  const int c = blockIdx.x;
+  const int j = threadIdx.x;
+  if (j < PSTRIDE) {
+    const double *p = d.partial + (size_t)c * d.nchunk * PSTRIDE + j;
+    double acc = 0.0;
+    for (int k = 0; k < d.nchunk; ++k) acc += p[(size_t)k * PSTRIDE];
+    s_E[j] = acc;
+    if (j < NLEV)
+      d.E_down[(size_t)c * NLEV + j] = acc;
+    else
+      d.E_up[(size_t)c * NLEV + (j - NLEV)] = acc;
+  }
+  __syncthreads();
+  if (j != 0) return;
+  const double *Ed = s_E, *Eu = s_E + NLEV;
+  double dE[NL];
+#pragma unroll
+  for (int i = 0; i < NL; ++i) dE[i] = Ed[i] - Ed[i + 1] + Eu[i + 1] - Eu[i];  // main.cpp:338
+  dE[NL - 1] += d.solar_irr + Ed[NL] - Eu[NL];                                  // main.cpp:341
+  double mx = dE[0];
+#pragma unroll
+  for (int i = 1; i < NL; ++i) mx = (mx < dE[i]) ? dE[i] : mx;  // signed max_element, main.cpp:157
+  const double heat_cap = 1004.0 * d.dp * 100.0;               // c_air * dp * 100, main.cpp:157,169
+  double dt = 5.0 / mx * heat_cap / 9.80665;                   // max_dT = 5 (float), main.cpp:82
+  if (dt > 3600 * 12) dt = 3600 * 12;                          // main.cpp:158-160
+  double Tlast = 0.0;
+#pragma unroll
+  for (int i = 0; i < NL; ++i) {
+    const double Tn = d.T[(size_t)c * NL + i] + dE[i] * dt * 9.80665 / heat_cap;  // main.cpp:169
+    d.T[(size_t)c * NL + i] = Tn;
+    d.dE[(size_t)c * NL + i] = dE[i];
+    Tlast = Tn;
+  }
+  d.Tsfc[c] = Tlast * d.conv[NL - 1];          // main.cpp:173
+  d.dt[c] = dt;
+  d.time_h[c] += (float)dt / 3600;             // main.cpp:581
+}
+
+// output_conv view of one column (main.cpp:536-546) into scratch: adjusted T, sorted theta.
+__global__ void k_profile(Dev d, int col, double *out) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  double T[NL], th[NL];
+#pragma unroll
+  for (int i = 0; i < NL; ++i) T[i] = d.T[(size_t)col * NL + i];
+  adjust(d.conv, T, th);
+#pragma unroll
+  for (int i = 0; i < NL; ++i) {
+    out[i] = T[i];
+    out[NL + i] = th[i];
+  }
+}
+
+// Optical depths of one column, [nspec][NL], for rcm_get_tau (parity of rows a5 / a9).
+__global__ __launch_bounds__(64) void k_tau(Dev d, int col, double *out) {
+  __shared__ RepwvlLds s;
+  __shared__ double s_scale[RCM_NSPEC_LBL * NL];
+  const int lane = threadIdx.x;
+  if (d.mode == MODE_REPWVL) {
+    repwvl_prologue(d, col, lane, s);
+  } else {
+    for (int i = lane; i < RCM_NSPEC_LBL * NL; i += 64) s_scale[i] = d.gas[(size_t)col * RCM_NSPEC_LBL * NL + i];
+  }
+  __syncthreads();
+  const long p = (long)blockIdx.x * 64 + lane;
+  if (p >= d.nspec) return;
+  if (d.mode == MODE_REPWVL) {
+#pragma unroll 1
+    for (int l = 0; l < NL; ++l) out[(size_t)p * NL + l] = repwvl_tau_layer(d, s, (int)p, l);
+  } else {
+#pragma unroll 4
+    for (int l = 0; l < NL; ++l) out[(size_t)p * NL + l] = lbl_tau_layer(d, s_scale, p, l);
+  }
+}
+
+// [ncol][NL+1] = (Tlayer, T_surface) for the one collective of the multi-GPU run.
+__global__ void k_pack(Dev d, double *out) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (size_t)d.ncol * NLEV) return;
+  const size_t c = i / NLEV, l = i % NLEV;
+  out[i] = (l < NL) ? d.T[c * NL + l] : d.Tsfc[c];
+}
+
+// lbl tables arrive [node][layer] (ASCII_file2xy2D layout); the kernels want band-fastest.
+__global__ void k_transpose_lbl(const double *in, double *out, long n_nodes, long ld) {
+  __shared__ double tile[NL][65];
+  const long b0 = (long)blockIdx.x * 64;
+  for (int i = threadIdx.x; i < 64 * NL; i += blockDim.x) {
+    const long b = b0 + i / NL;
+    const int l = i % NL;
+    tile[l][i / NL] = (b < n_nodes) ? in[b * NL + l] : 0.0;
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < 64 * NL; i += blockDim.x) {
+    const int l = i / 64, k = i % 64;
+    if (b0 + k < ld) out[(size_t)l * ld + b0 + k] = tile[l][k];
+  }
+}
+
+}  // namespace rcm
+
+// =============================================================================================
+// Host side: the handle and the C ABI.
+// =============================================================================================
+using rcm::Dev;
+using rcm::fail;
+using rcm::NL;
+using rcm::NLEV;
+
+#define HIPCK(call)                                                                       \
+  do {                                                                                    \
+    hipError_t e_ = (call);                                                               \
+    if (e_ != hipSuccess)                                                                 \
+      return fail(RCM_ERR_HIP, std::string(#call) + ": " + hipGetErrorString(e_));        \
+  } while (0)
+
+struct rcm_ensemble {
+  int ncol = 0, nlayer = 0, nangle = 0, device = 0, mode = rcm::MODE_NONE;
+  hipStream_t stream = nullptr;
+  bool own_stream = false;
+  bool have_grid = false, have_columns = false;
+  long long step_index = 0;  // the reference's loop variable i (main.cpp:531)
+  int user_chunks = 0;
+  int exp_variant = 1, cube = 1;
+  std::vector<double> plevel, player, conv;
+  std::vector<void *> allocs;
+  Dev d{};
+  double *scratch = nullptr;  // 2*NL doubles
+  double *partial_buf = nullptr;
+  // repwvl host copies needed to (re)derive per-layer constants
+  std::vector<double> p_grid;
+  int *d_ip = nullptr;
+  double *d_delP = nullptr, *d_numDens = nullptr;
+  // timing
+  bool timing = false;
+  std::vector<std::pair<hipEvent_t, hipEvent_t>> events;
+  size_t events_used = 0;
+};
+
+namespace {
+
+template <typename T>
+int dev_alloc(rcm_ensemble *h, T **p, size_t n) {
+  void *q = nullptr;
+  HIPCK(hipMalloc(&q, (n ? n : 1) * sizeof(T)));
+  h->allocs.push_back(q);
+  *p = (T *)q;
+  return RCM_OK;
+}
+
+template <typename T>
+int dev_upload(rcm_ensemble *h, T **p, const T *src, size_t n) {
+  if (int rc = dev_alloc(h, p, n)) return rc;
+  HIPCK(hipMemcpyAsync(*p, src, n * sizeof(T), hipMemcpyHostToDevice, h->stream));
+  HIPCK(hipStreamSynchronize(h->stream));
+  return RCM_OK;
+}
+
+int use_device(rcm_ensemble *h) {
+  HIPCK(hipSetDevice(h->device));
+  return RCM_OK;
+}
+
+// Per-layer constants of read_tau that depend only on the pressure grid
+// (repwvl_thermal.cpp:68-73, 201-202, 214, 226, 240), top-first layer index.
+int derive_repwvl_layers(rcm_ensemble *h) {
+  if (h->mode != rcm::MODE_REPWVL || !h->have_grid) return RCM_OK;
+  const double avog = 6.02214076e23, molMassAir = 0.0289647, earthAccel = 9.80665;
+  std::vector<int> ip(NL);
+  std::vector<double> delP(NL), numDens(NL);
+  const int np = (int)h->p_grid.size();
+  for (int o = 0; o < NL; ++o) {
+    const double p_up = h->plevel[o] * 100.0, p_dn = h->plevel[o + 1] * 100.0;  // Pa
+    const double midP = (p_up + p_dn) / 2;                                       // :214
+    // LowerPos(p_ref, midP), :19-45
+    auto sgn = [](double v) { return (0.0 < v) - (v < 0.0); };
+    int lp = 0, sign = sgn(h->p_grid[0] - midP);
+    for (int p = 1; p != np; ++p) {
+      const double delta = h->p_grid[p] - midP;
+      if (sign != sgn(delta) || p == np - 1) {
+        lp = p - 1;
+        break;
+      }
+      sign = sgn(delta);
+    }
+    ip[o] = lp;
+    delP[o] = (midP - h->p_grid[lp]) / (h->p_grid[lp + 1] - h->p_grid[lp]);  // :240
+    numDens[o] = (p_dn - p_up) * avog / molMassAir / earthAccel;              // :202
+  }
+  HIPCK(hipMemcpyAsync(h->d_ip, ip.data(), NL * sizeof(int), hipMemcpyHostToDevice, h->stream));
+  HIPCK(hipMemcpyAsync(h->d_delP, delP.data(), NL * sizeof(double), hipMemcpyHostToDevice, h->stream));
+  HIPCK(hipMemcpyAsync(h->d_numDens, numDens.data(), NL * sizeof(double), hipMemcpyHostToDevice, h->stream));
+  HIPCK(hipStreamSynchronize(h->stream));
+  return RCM_OK;
+}
+
+// Spectral chunking: enough waves to fill 256 CUs x 8 resident waves several times over, but
+// never more chunks than 64-point rows.  Pure function of (ncol, nspec, user override).
+void choose_chunks(int ncol, int nspec, int user_chunks, int *nchunk_out, int *chunk_len_out) {
+  const int rows = (nspec + 63) / 64;
+  int nchunk;
+  if (user_chunks > 0) {
+    nchunk = user_chunks;
+  } else {
+    const long target_waves = 256L * 8 * 4;
+    nchunk = (int)((target_waves + ncol - 1) / ncol);
+  }
+  if (nchunk > rows) nchunk = rows;
+  if (nchunk < 1) nchunk = 1;
+  const int rows_per_chunk = (rows + nchunk - 1) / nchunk;
+  *chunk_len_out = rows_per_chunk * 64;
+  *nchunk_out = (rows + rows_per_chunk - 1) / rows_per_chunk;
+}
+
+int ensure_partials(rcm_ensemble *h) {
+  choose_chunks(h->ncol, h->d.nspec, h->user_chunks, &h->d.nchunk, &h->d.chunk_len);
+  if (h->partial_buf) {
+    HIPCK(hipStreamSynchronize(h->stream));
+    HIPCK(hipFree(h->partial_buf));
+    h->partial_buf = nullptr;
+  }
+  HIPCK(hipMalloc((void **)&h->partial_buf, (size_t)h->ncol * h->d.nchunk * rcm::PSTRIDE * sizeof(double)));
+  h->d.partial = h->partial_buf;
+  return RCM_OK;
+}
+
+template <int EXPV, int CUBE>
+void launch_rt(rcm_ensemble *h, int blocks) {
+  if (h->mode == rcm::MODE_LBL)
+    hipLaunchKernelGGL((rcm::k_rt_lbl<EXPV, CUBE>), dim3(blocks), dim3(64 * rcm::WPB), 0, h->stream, h->d);
+  else
+    hipLaunchKernelGGL((rcm::k_rt_repwvl<EXPV, CUBE>), dim3(blocks), dim3(64 * rcm::WPB), 0, h->stream, h->d);
+}
+
+int launch_step(rcm_ensemble *h) {
+  Dev &d = h->d;
+  const int first = (h->step_index == 0) ? 1 : 0;
+  hipLaunchKernelGGL(rcm::k_pre, dim3((h->ncol + 127) / 128), dim3(128), 0, h->stream, d, first);
+  const int ncg = (h->ncol + rcm::WPB - 1) / rcm::WPB;
+  const int blocks = ncg * d.nchunk;
+  hipEvent_t e0 = nullptr, e1 = nullptr;
+  if (h->timing) {
+    if (h->events_used == h->events.size()) {
+      hipEvent_t a, b;
+      HIPCK(hipEventCreate(&a));
+      HIPCK(hipEventCreate(&b));
+      h->events.emplace_back(a, b);
+    }
+    e0 = h->events[h->events_used].first;
+    e1 = h->events[h->events_used].second;
+    ++h->events_used;
+    HIPCK(hipEventRecord(e0, h->stream));
+  }
+  if (h->exp_variant == 0 && !h->cube)
+    launch_rt<0, 0>(h, blocks);
+  else if (h->exp_variant == 0 && h->cube)
+    launch_rt<0, 1>(h, blocks);
+  else if (h->exp_variant == 1 && !h->cube)
+    launch_rt<1, 0>(h, blocks);
+  else
+    launch_rt<1, 1>(h, blocks);
+  if (h->timing) HIPCK(hipEventRecord(e1, h->stream));
+  hipLaunchKernelGGL(rcm::k_post, dim3(h->ncol), dim3(64), 0, h->stream, d);
+  HIPCK(hipGetLastError());
+  ++h->step_index;
+  return RCM_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int rcm_create(int ncol, int nlayer, int nangle, int device, void *stream, rcm_ensemble **out) {
+  if (!out) return fail(RCM_ERR_ARG, "rcm_create: out is NULL");
+  *out = nullptr;
+  if (ncol < 1) return fail(RCM_ERR_ARG, "rcm_create: ncol must be >= 1");
+  if (nlayer != NL) return fail(RCM_ERR_ARG, "rcm_create: kernels are specialised for nlayer == 20 (main.cpp:78)");
+  if (nangle < 1 || nangle > 64) return fail(RCM_ERR_ARG, "rcm_create: nangle must be in 1..64");
+  int ndev = 0;
+  hipError_t e = hipGetDeviceCount(&ndev);
+  if (e != hipSuccess || ndev < 1)
+    return fail(RCM_ERR_HIP, std::string("rcm_create: no HIP device (this library has no CPU path): hipGetDeviceCount -> ") +
+                                 hipGetErrorString(e) + ", count " + std::to_string(ndev));
+  if (device < 0 || device >= ndev) return fail(RCM_ERR_ARG, "rcm_create: device index out of range");
+  rcm_ensemble *h = new (std::nothrow) rcm_ensemble();
+  if (!h) return fail(RCM_ERR_NOMEM, "rcm_create: out of memory");
+  h->ncol = ncol, h->nlayer = nlayer, h->nangle = nangle, h->device = device;
+  if (const char *v = std::getenv("RCM_EXP_VARIANT")) h->exp_variant = std::atoi(v) ? 1 : 0;
+  if (const char *v = std::getenv("RCM_CUBE")) h->cube = std::atoi(v) ? 1 : 0;
+  auto bail = [&](int rc) {
+    rcm_destroy(h);
+    return rc;
+  };
+  if (int rc = use_device(h)) return bail(rc);
+  if (stream) {
+    h->stream = (hipStream_t)stream;
+  } else {
+    if (hipStreamCreate(&h->stream) != hipSuccess) return bail(fail(RCM_ERR_HIP, "hipStreamCreate failed"));
+    h->own_stream = true;
+  }
+  Dev &d = h->d;
+  d.ncol = ncol, d.nangle = nangle, d.mode = rcm::MODE_NONE;
+  d.cloud_layer = 17;       // main.cpp:92
+  d.cloud_tau = 2.0 / 2.0;  // tau_s / 2, main.cpp:86,267
+  d.solar_irr = 0.0;
+  d.dp = 1000.0 / (double)nlayer;  // main.cpp:355
+  d.sigdpi = 5.67032E-8 / M_PI;    // cplkavg.cpp:121,134
+  const size_t nT = (size_t)ncol * NL, nE = (size_t)ncol * NLEV;
+  int rc = 0;
+  rc = rc ? rc : dev_alloc(h, &d.T, nT);
+  rc = rc ? rc : dev_alloc(h, &d.Ttau, nT);
+  rc = rc ? rc : dev_alloc(h, &d.Tsfc, (size_t)ncol);
+  rc = rc ? rc : dev_alloc(h, &d.dt, (size_t)ncol);
+  rc = rc ? rc : dev_alloc(h, &d.time_h, (size_t)ncol);
+  rc = rc ? rc : dev_alloc(h, (double **)&d.rel_hum, nT);
+  rc = rc ? rc : dev_alloc(h, &d.E_down, nE);
+  rc = rc ? rc : dev_alloc(h, &d.E_up, nE);
+  rc = rc ? rc : dev_alloc(h, &d.dE, nT);
+  rc = rc ? rc : dev_alloc(h, &h->scratch, (size_t)2 * NL);
+  rc = rc ? rc : dev_alloc(h, (double **)&d.player, (size_t)NL);
+  rc = rc ? rc : dev_alloc(h, (double **)&d.conv, (size_t)NL);
+  rc = rc ? rc : dev_alloc(h, &h->d_ip, (size_t)NL);
+  rc = rc ? rc : dev_alloc(h, &h->d_delP, (size_t)NL);
+  rc = rc ? rc : dev_alloc(h, &h->d_numDens, (size_t)NL);
+  if (rc) return bail(rc);
+  d.ip = h->d_ip, d.delP = h->d_delP, d.numDens = h->d_numDens;
+  // angles: mu_i = dmu/2 + dmu*i (main.cpp:356,482); weight 2*pi*mu*dmu (main.cpp:302,308,313)
+  std::vector<double> ang(2 * (size_t)nangle);
+  const double dmu = 1.0 / (double)nangle;
+  for (int i = 0; i < nangle; ++i) {
+    const double mu = dmu / 2.0 + dmu * (double)i;
+    ang[i] = 1.0 / mu;
+    ang[nangle + i] = 2 * M_PI * mu * dmu;
+  }
+  if ((rc = dev_upload(h, (double **)&d.ang, ang.data(), ang.size()))) return bail(rc);
+  hipError_t me = hipMemsetAsync(d.time_h, 0, ncol * sizeof(float), h->stream);
+  if (me == hipSuccess) me = hipMemsetAsync(d.dt, 0, ncol * sizeof(double), h->stream);
+  if (me == hipSuccess) me = hipMemsetAsync(d.E_down, 0, nE * sizeof(double), h->stream);
+  if (me == hipSuccess) me = hipMemsetAsync(d.E_up, 0, nE * sizeof(double), h->stream);
+  if (me == hipSuccess) me = hipMemsetAsync(d.dE, 0, nT * sizeof(double), h->stream);
+  if (me == hipSuccess) me = hipStreamSynchronize(h->stream);
+  if (me != hipSuccess) return bail(fail(RCM_ERR_HIP, std::string("rcm_create: ") + hipGetErrorString(me)));
+  *out = h;
+  return RCM_OK;
+}
+
+int rcm_destroy(rcm_ensemble *h) {
+  if (!h) return fail(RCM_ERR_ARG, "rcm_destroy: NULL handle");
+  (void)hipSetDevice(h->device);
+  if (h->stream) (void)hipStreamSynchronize(h->stream);
+  for (void *p : h->allocs) (void)hipFree(p);
+  if (h->partial_buf) (void)hipFree(h->partial_buf);
+  for (auto &ev : h->events) {
+    (void)hipEventDestroy(ev.first);
+    (void)hipEventDestroy(ev.second);
+  }
+  if (h->own_stream && h->stream) (void)hipStreamDestroy(h->stream);
+  delete h;
+  return RCM_OK;
+}
+
+int rcm_set_grid(rcm_ensemble *h, const double *plevel_hPa) {
+  if (!h || !plevel_hPa) return fail(RCM_ERR_ARG, "rcm_set_grid: bad argument");
+  if (int rc = use_device(h)) return rc;
+  h->plevel.assign(plevel_hPa, plevel_hPa + NLEV);
+  h->player.resize(NL);
+  h->conv.resize(NL);
+  for (int i = 0; i < NL; ++i) {
+    h->player[i] = (plevel_hPa[i] + plevel_hPa[i + 1]) / 2.0;  // main.cpp:472
+    if (!(h->player[i] > 0)) return fail(RCM_ERR_ARG, "rcm_set_grid: layer pressure must be positive");
+    h->conv[i] = std::pow(1000.0 / h->player[i], 2.0 / 7.0);   // main.cpp:474, kappa main.cpp:66
+  }
+  HIPCK(hipMemcpyAsync((void *)h->d.player, h->player.data(), NL * sizeof(double), hipMemcpyHostToDevice, h->stream));
+  HIPCK(hipMemcpyAsync((void *)h->d.conv, h->conv.data(), NL * sizeof(double), hipMemcpyHostToDevice, h->stream));
+  HIPCK(hipStreamSynchronize(h->stream));
+  h->have_grid = true;
+  return derive_repwvl_layers(h);
+}
+
+int rcm_set_forcing(rcm_ensemble *h, double solar_irr, int cloud_layer, double cloud_tau) {
+  if (!h || cloud_layer < -1 || cloud_layer >= NL) return fail(RCM_ERR_ARG, "rcm_set_forcing: bad argument");
+  h->d.solar_irr = solar_irr;
+  h->d.cloud_layer = cloud_layer;
+  h->d.cloud_tau = cloud_tau;
+  return RCM_OK;
+}
+
+int rcm_set_repwvl_tables(rcm_ensemble *h, int n_tpert, int n_species, int n_wvl, int n_p,
+                          const double *p_grid, const double *t_ref, const double *t_pert,
+                          const double *wvl, const double *weight, const double *xsec) {
+  if (!h || !p_grid || !t_ref || !t_pert || !wvl || !weight || !xsec)
+    return fail(RCM_ERR_ARG, "rcm_set_repwvl_tables: NULL argument");
+  if (n_species != RCM_NSPEC_REPWVL) return fail(RCM_ERR_ARG, "rcm_set_repwvl_tables: n_species must be 9");
+  if (n_tpert < 2 || n_p < 2 || n_wvl < 1) return fail(RCM_ERR_ARG, "rcm_set_repwvl_tables: bad dimensions");
+  if (h->mode != rcm::MODE_NONE) return fail(RCM_ERR_STATE, "rcm_set_repwvl_tables: tables already set");
+  if (int rc = use_device(h)) return rc;
+  Dev &d = h->d;
+  // re-lay out [t][s][w][p] -> [t][s][p][w] so that a wave's 64 wavelengths are contiguous
+  std::vector<double> xt((size_t)n_tpert * n_species * n_p * n_wvl);
+  for (int t = 0; t < n_tpert; ++t)
+    for (int s = 0; s < n_species; ++s)
+      for (int w = 0; w < n_wvl; ++w)
+        for (int p = 0; p < n_p; ++p)
+          xt[(((size_t)t * n_species + s) * n_p + p) * n_wvl + w] =
+              xsec[(((size_t)t * n_species + s) * n_wvl + w) * n_p + p];
+  // per-wavelength Planck constants in the reference's operation order (main.cpp:188-191)
+  std::vector<double> pnum(n_wvl), lam5(n_wvl), lkb(n_wvl);
+  const double hP = 6.62607e-34, cL = 299792458, kB = 1.380649e-23;  // main.cpp:70-72
+  for (int w = 0; w < n_wvl; ++w) {
+    double lam = wvl[w];
+    lam *= 1e-9;
+    pnum[w] = weight[w] * 2 * hP * std::pow(cL, 2);
+    lam5[w] = std::pow(lam, 5);
+    lkb[w] = lam * kB;
+  }
+  int rc = 0;
+  rc = rc ? rc : dev_upload(h, (double **)&d.xsec, xt.data(), xt.size());
+  rc = rc ? rc : dev_upload(h, (double **)&d.t_ref, t_ref, (size_t)n_p);
+  rc = rc ? rc : dev_upload(h, (double **)&d.t_pert, t_pert, (size_t)n_tpert);
+  rc = rc ? rc : dev_upload(h, (double **)&d.pnum, pnum.data(), (size_t)n_wvl);
+  rc = rc ? rc : dev_upload(h, (double **)&d.lam5, lam5.data(), (size_t)n_wvl);
+  rc = rc ? rc : dev_upload(h, (double **)&d.lkb, lkb.data(), (size_t)n_wvl);
+  if (rc) return rc;
+  h->p_grid.assign(p_grid, p_grid + n_p);
+  d.n_tpert = n_tpert, d.n_species = n_species, d.n_p = n_p, d.n_wvl = n_wvl;
+  d.nspec = n_wvl;
+  d.ngas = RCM_NSPEC_REPWVL;
+  d.mode = h->mode = rcm::MODE_REPWVL;
+  d.species_mask = 0x1ff;
+  return derive_repwvl_layers(h);
+}
+
+int rcm_set_lbl_tables(rcm_ensemble *h, int n_nodes, const double *wvl,
+                       const double *const tabs[RCM_NSPEC_LBL], const double *h2o_ref) {
+  if (!h || !wvl || !tabs || !h2o_ref) return fail(RCM_ERR_ARG, "rcm_set_lbl_tables: NULL argument");
+  if (n_nodes < 2) return fail(RCM_ERR_ARG, "rcm_set_lbl_tables: need at least 2 wavelength nodes");
+  for (int s = 0; s < RCM_NSPEC_LBL; ++s)
+    if (!tabs[s]) return fail(RCM_ERR_ARG, "rcm_set_lbl_tables: NULL species table");
+  for (int i = 0; i + 1 < n_nodes; ++i)  // cplkavg.cpp:144-146 would exit(1) on these
+    if (!(wvl[i] > 0) || !(wvl[i] < wvl[i + 1]))
+      return fail(RCM_ERR_ARG, "rcm_set_lbl_tables: wavelengths must be positive and strictly increasing");
+  for (int l = 0; l < NL; ++l)
+    if (!(h2o_ref[l] > 0)) return fail(RCM_ERR_ARG, "rcm_set_lbl_tables: h2o_ref must be positive");
+  if (h->mode != rcm::MODE_NONE) return fail(RCM_ERR_STATE, "rcm_set_lbl_tables: tables already set");
+  if (int rc = use_device(h)) return rc;
+  Dev &d = h->d;
+  const long nband = n_nodes - 1;
+  const long ld = (nband + 63) / 64 * 64;
+  double *tab = nullptr, *stage = nullptr;
+  if (int rc = dev_alloc(h, &tab, (size_t)RCM_NSPEC_LBL * NL * ld)) return rc;
+  HIPCK(hipMalloc((void **)&stage, (size_t)n_nodes * NL * sizeof(double)));
+  for (int s = 0; s < RCM_NSPEC_LBL; ++s) {
+    hipError_t e = hipMemcpyAsync(stage, tabs[s], (size_t)n_nodes * NL * sizeof(double), hipMemcpyHostToDevice, h->stream);
+    if (e == hipSuccess) {
+      hipLaunchKernelGGL(rcm::k_transpose_lbl, dim3((unsigned)(ld / 64)), dim3(256), 0, h->stream, stage,
+                         tab + (size_t)s * NL * ld, (long)n_nodes, ld);
+      e = hipStreamSynchronize(h->stream);
+    }
+    if (e != hipSuccess) {
+      (void)hipFree(stage);
+      return fail(RCM_ERR_HIP, std::string("rcm_set_lbl_tables: ") + hipGetErrorString(e));
+    }
+  }
+  (void)hipFree(stage);
+  int rc = 0;
+  rc = rc ? rc : dev_upload(h, (double **)&d.lbl_wvl, wvl, (size_t)n_nodes);
+  rc = rc ? rc : dev_upload(h, (double **)&d.h2o_ref, h2o_ref, (size_t)NL);
+  if (rc) return rc;
+  d.lbl_tab = tab;
+  d.lbl_ld = ld;
+  d.nspec = (int)nband;
+  d.ngas = RCM_NSPEC_LBL;
+  d.mode = h->mode = rcm::MODE_LBL;
+  return RCM_OK;
+}
+
+int rcm_set_columns(rcm_ensemble *h, const double *Tlayer0, const double *T_surface0,
+                    const double *gas, const double *rel_hum) {
+  if (!h || !Tlayer0 || !T_surface0 || !gas || !rel_hum) return fail(RCM_ERR_ARG, "rcm_set_columns: NULL argument");
+  if (h->mode == rcm::MODE_NONE) return fail(RCM_ERR_STATE, "rcm_set_columns: set the spectral tables first");
+  if (int rc = use_device(h)) return rc;
+  Dev &d = h->d;
+  const size_t nT = (size_t)h->ncol * NL, nG = nT * d.ngas;
+  if (!d.gas)
+    if (int rc = dev_alloc(h, &d.gas, nG)) return rc;
+  if (h->mode == rcm::MODE_REPWVL) {  // species whose mixing ratio is 0 everywhere add exactly +0
+    unsigned mask = 0;
+    for (int c = 0; c < h->ncol; ++c)
+      for (int s = 0; s < RCM_NSPEC_REPWVL; ++s)
+        for (int l = 0; l < NL; ++l)
+          if (gas[((size_t)c * RCM_NSPEC_REPWVL + s) * NL + l] != 0.0) mask |= 1u << s;
+    d.species_mask = mask | 1u;  // H2O always: the feedback rewrites it
+  }
+  HIPCK(hipMemcpyAsync(d.T, Tlayer0, nT * sizeof(double), hipMemcpyHostToDevice, h->stream));
+  HIPCK(hipMemcpyAsync(d.Ttau, Tlayer0, nT * sizeof(double), hipMemcpyHostToDevice, h->stream));
+  HIPCK(hipMemcpyAsync(d.Tsfc, T_surface0, h->ncol * sizeof(double), hipMemcpyHostToDevice, h->stream));
+  HIPCK(hipMemcpyAsync(d.gas, gas, nG * sizeof(double), hipMemcpyHostToDevice, h->stream));
+  HIPCK(hipMemcpyAsync((void *)d.rel_hum, rel_hum, nT * sizeof(double), hipMemcpyHostToDevice, h->stream));
+  HIPCK(hipMemsetAsync(d.time_h, 0, h->ncol * sizeof(float), h->stream));
+  HIPCK(hipMemsetAsync(d.dt, 0, h->ncol * sizeof(double), h->stream));
+  HIPCK(hipStreamSynchronize(h->stream));
+  h->step_index = 0;
+  h->have_columns = true;
+  return RCM_OK;
+}
+
+int rcm_set_spectral_chunks(rcm_ensemble *h, int nchunk) {
+  if (!h || nchunk < 0) return fail(RCM_ERR_ARG, "rcm_set_spectral_chunks: bad argument");
+  h->user_chunks = nchunk;
+  h->d.partial = nullptr;  // re-derive on the next step
+  return RCM_OK;
+}
+
+int rcm_get_spectral_chunks(rcm_ensemble *h) {
+  if (!h || h->mode == rcm::MODE_NONE) return fail(RCM_ERR_STATE, "rcm_get_spectral_chunks: tables not set");
+  int nchunk = 0, len = 0;
+  choose_chunks(h->ncol, h->d.nspec, h->user_chunks, &nchunk, &len);
+  return nchunk;
+}
+
+int rcm_step(rcm_ensemble *h, int nsteps) {
+  if (!h || nsteps < 0) return fail(RCM_ERR_ARG, "rcm_step: bad argument");
+  if (h->mode == rcm::MODE_NONE || !h->have_grid || !h->have_columns)
+    return fail(RCM_ERR_STATE, "rcm_step: grid, spectral tables and columns must be set first");
+  if (int rc = use_device(h)) return rc;
+  if (!h->d.partial)
+    if (int rc = ensure_partials(h)) return rc;
+  for (int i = 0; i < nsteps; ++i)
+    if (int rc = launch_step(h)) return rc;
+  return RCM_OK;
+}
+
+int rcm_sync(rcm_ensemble *h) {
+  if (!h) return fail(RCM_ERR_ARG, "rcm_sync: NULL handle");
+  if (int rc = use_device(h)) return rc;
+  HIPCK(hipStreamSynchronize(h->stream));
+  return RCM_OK;
+}
+
+static int copy_out(rcm_ensemble *h, void *dst, const void *src, size_t bytes) {
+  if (!dst) return RCM_OK;
+  HIPCK(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, h->stream));
+  return RCM_OK;
+}
+
+int rcm_get_state(rcm_ensemble *h, double *Tlayer, double *T_surface, float *time_h, double *timestep) {
+  if (!h) return fail(RCM_ERR_ARG, "rcm_get_state: NULL handle");
+  if (int rc = use_device(h)) return rc;
+  int rc = 0;
+  rc = rc ? rc : copy_out(h, Tlayer, h->d.T, (size_t)h->ncol * NL * sizeof(double));
+  rc = rc ? rc : copy_out(h, T_surface, h->d.Tsfc, h->ncol * sizeof(double));
+  rc = rc ? rc : copy_out(h, time_h, h->d.time_h, h->ncol * sizeof(float));
+  rc = rc ? rc : copy_out(h, timestep, h->d.dt, h->ncol * sizeof(double));
+  if (rc) return rc;
+  HIPCK(hipStreamSynchronize(h->stream));
+  return RCM_OK;
+}
+
+int rcm_get_fluxes(rcm_ensemble *h, double *E_down, double *E_up, double *dE) {
+  if (!h) return fail(RCM_ERR_ARG, "rcm_get_fluxes: NULL handle");
+  if (int rc = use_device(h)) return rc;
+  int rc = 0;
+  rc = rc ? rc : copy_out(h, E_down, h->d.E_down, (size_t)h->ncol * NLEV * sizeof(double));
+  rc = rc ? rc : copy_out(h, E_up, h->d.E_up, (size_t)h->ncol * NLEV * sizeof(double));
+  rc = rc ? rc : copy_out(h, dE, h->d.dE, (size_t)h->ncol * NL * sizeof(double));
+  if (rc) return rc;
+  HIPCK(hipStreamSynchronize(h->stream));
+  return RCM_OK;
+}
+
+int rcm_get_profile(rcm_ensemble *h, int col, double *Tlayer_adj, double *theta, float *time_h) {
+  if (!h || col < 0 || col >= h->ncol) return fail(RCM_ERR_ARG, "rcm_get_profile: bad argument");
+  if (!h->have_grid || !h->have_columns) return fail(RCM_ERR_STATE, "rcm_get_profile: grid/columns not set");
+  if (int rc = use_device(h)) return rc;
+  hipLaunchKernelGGL(rcm::k_profile, dim3(1), dim3(64), 0, h->stream, h->d, col, h->scratch);
+  HIPCK(hipGetLastError());
+  int rc = 0;
+  rc = rc ? rc : copy_out(h, Tlayer_adj, h->scratch, NL * sizeof(double));
+  rc = rc ? rc : copy_out(h, theta, h->scratch + NL, NL * sizeof(double));
+  rc = rc ? rc : copy_out(h, time_h, h->d.time_h + col, sizeof(float));
+  if (rc) return rc;
+  HIPCK(hipStreamSynchronize(h->stream));
+  return RCM_OK;
+}
+
+int rcm_nspectral(rcm_ensemble *h) {
+  if (!h || h->mode == rcm::MODE_NONE) return fail(RCM_ERR_STATE, "rcm_nspectral: tables not set");
+  return h->d.nspec;
+}
+
+int rcm_get_tau(rcm_ensemble *h, int col, double *tau) {
+  if (!h || !tau || col < 0 || col >= h->ncol) return fail(RCM_ERR_ARG, "rcm_get_tau: bad argument");
+  if (h->mode == rcm::MODE_NONE || !h->have_grid || !h->have_columns)
+    return fail(RCM_ERR_STATE, "rcm_get_tau: grid, tables and columns must be set first");
+  if (int rc = use_device(h)) return rc;
+  const size_t n = (size_t)h->d.nspec * NL;
+  double *buf = nullptr;
+  HIPCK(hipMalloc((void **)&buf, n * sizeof(double)));
+  hipLaunchKernelGGL(rcm::k_tau, dim3((h->d.nspec + 63) / 64), dim3(64), 0, h->stream, h->d, col, buf);
+  hipError_t e = hipGetLastError();
+  if (e == hipSuccess) e = hipMemcpyAsync(tau, buf, n * sizeof(double), hipMemcpyDeviceToHost, h->stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+  (void)hipFree(buf);
+  if (e != hipSuccess) return fail(RCM_ERR_HIP, std::string("rcm_get_tau: ") + hipGetErrorString(e));
+  return RCM_OK;
+}
+
+int rcm_get_gas(rcm_ensemble *h, double *gas) {
+  if (!h || !gas) return fail(RCM_ERR_ARG, "rcm_get_gas: bad argument");
+  if (!h->have_columns) return fail(RCM_ERR_STATE, "rcm_get_gas: columns not set");
+  if (int rc = use_device(h)) return rc;
+  if (int rc = copy_out(h, gas, h->d.gas, (size_t)h->ncol * h->d.ngas * NL * sizeof(double))) return rc;
+  HIPCK(hipStreamSynchronize(h->stream));
+  return RCM_OK;
+}
+
+int rcm_pack_state(rcm_ensemble *h, void *dev_out) {
+  if (!h || !dev_out) return fail(RCM_ERR_ARG, "rcm_pack_state: bad argument");
+  if (!h->have_columns) return fail(RCM_ERR_STATE, "rcm_pack_state: columns not set");
+  if (int rc = use_device(h)) return rc;
+  const size_t n = (size_t)h->ncol * NLEV;
+  hipLaunchKernelGGL(rcm::k_pack, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, h->stream, h->d, (double *)dev_out);
+  HIPCK(hipGetLastError());
+  return RCM_OK;
+}
+
+int rcm_set_rt_timing(rcm_ensemble *h, int enable) {
+  if (!h) return fail(RCM_ERR_ARG, "rcm_set_rt_timing: NULL handle");
+  h->timing = enable != 0;
+  h->events_used = 0;
+  return RCM_OK;
+}
+
+int rcm_get_rt_timing(rcm_ensemble *h, double *ms_total, int *launches) {
+  if (!h) return fail(RCM_ERR_ARG, "rcm_get_rt_timing: NULL handle");
+  if (int rc = use_device(h)) return rc;
+  HIPCK(hipStreamSynchronize(h->stream));
+  double total = 0.0;
+  for (size_t i = 0; i < h->events_used; ++i) {
+    float ms = 0.f;
+    HIPCK(hipEventElapsedTime(&ms, h->events[i].first, h->events[i].second));
+    total += ms;
+  }
+  if (ms_total) *ms_total = total;
+  if (launches) *launches = (int)h->events_used;
+  h->events_used = 0;
+  return RCM_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,32 @@
+"""Multi-GPU plumbing: columns are independent (no horizontal coupling anywhere in main.cpp), so the
+ensemble is cut into contiguous blocks, one per rank, and the only exchange is ONE all-gather of
+(Tlayer[20], T_surface) per column at the end.  torch.distributed is the
+transport ('nccl' = RCCL over xGMI on the MI355X node, 'gloo' in the CPU tests)."""
+import numpy as np
+
+
+def shard_bounds(ncol_total, rank, world):
+    """Contiguous block [lo, hi) of rank `rank`; every rank but the last gets ceil(N/world)."""
+    per = (ncol_total + world - 1) // world
+    lo = min(rank * per, ncol_total)
+    return lo, min(lo + per, ncol_total)
+
+
+def gather_state(local_packed, ncol_total, world, dist=None):
+    """All-gathers the packed [ncol_local][nlev] state blocks into [ncol_total][nlev] on every rank.
+    `local_packed` is a torch tensor on the rank's device (or CPU for gloo).  Shards are padded to
+    ceil(N/world) rows so that one equal-size all-gather does it."""
+    import torch
+    if world == 1:
+        return local_packed
+    if dist is None:
+        import torch.distributed as dist
+    per = (ncol_total + world - 1) // world
+    nlev = local_packed.shape[1]
+    send = local_packed
+    if send.shape[0] < per:
+        pad = torch.zeros((per - send.shape[0], nlev), dtype=send.dtype, device=send.device)
+        send = torch.cat([send, pad], dim=0)
+    recv = torch.empty((world * per, nlev), dtype=send.dtype, device=send.device)
+    dist.all_gather_into_tensor(recv, send.contiguous())
+    return recv[:ncol_total]

@@ -1,0 +1,104 @@
+"""Host logic that turns one atmosphere profile into an ensemble of perturbed columns, and the
+seeded synthetic lbl.arts spectra used while the real `lbl.*.asc` files are unavailable
+(/root/reference/.MISSING_LARGE_BLOBS).  Pure numpy + the C-ABI host functions; no device work.
+"""
+from dataclasses import dataclass
+
+import numpy as np
+
+from . import api
+
+SEED = 20260104
+LBL_SPECIES = ("co2", "h2o", "o3", "ch4", "n2o")  # lbl.arts/README:5, table order of rcm_set_lbl_tables
+
+
+@dataclass
+class EnsembleSpec:
+    """Per-column perturbations: CO2 multiplier (main.cpp:452 `factor`),
+    relative-humidity multiplier, initial surface temperature (main.cpp:357)."""
+    co2_factor: np.ndarray
+    rh_scale: np.ndarray
+    T_surface0: np.ndarray
+
+    @property
+    def ncol(self):
+        return self.co2_factor.size
+
+    def shard(self, rank, world):
+        """Contiguous block of columns for `rank`."""
+        per = (self.ncol + world - 1) // world
+        lo, hi = min(rank * per, self.ncol), min((rank + 1) * per, self.ncol)
+        return EnsembleSpec(self.co2_factor[lo:hi], self.rh_scale[lo:hi], self.T_surface0[lo:hi])
+
+
+def perturbation_sweep(ncol, perturb_rh=False, perturb_ts=False, seed=SEED, first=0, total=None):
+    """CO2 factor linspace(0.5, 4.0, total) (200..1600 ppm); optional RH scale 1+0.1u and
+    T_surface0 288.2+2u, u ~ U(-1,1).  A single column is the unperturbed reference column.
+    `first`/`total` select a window of a larger sweep (multi-GPU sharding)."""
+    total = ncol if total is None else total
+    if total == 1:
+        co2 = np.array([1.0])
+    else:
+        co2 = np.linspace(0.5, 4.0, total)[first:first + ncol]
+    rng = np.random.Generator(np.random.PCG64(seed))
+    u = rng.uniform(-1.0, 1.0, size=(total, 2))[first:first + ncol]
+    rh = 1.0 + 0.1 * u[:, 0] if perturb_rh else np.ones(ncol)
+    ts = 288.2 + 2.0 * u[:, 1] if perturb_ts else np.full(ncol, 288.2)
+    return EnsembleSpec(np.ascontiguousarray(co2), np.ascontiguousarray(rh), np.ascontiguousarray(ts))
+
+
+def build_columns(atm_cols, spec, mode):
+    """Per-column initial state in the layout of rcm_set_columns.  mode: 'repwvl' or 'lbl'.
+    Every column goes through rcm_column_init (main.cpp:439-485)."""
+    base = api.column_init(atm_cols, 1.0, 1.0)
+    nl = base["Tlayer"].size
+    ncol = spec.ncol
+    ngas = 9 if mode == "repwvl" else 5
+    gas = np.zeros((ncol, ngas, nl))
+    rel_hum = np.zeros((ncol, nl))
+    Tlayer0 = np.tile(base["Tlayer"], (ncol, 1))
+    for c in range(ncol):
+        ci = api.column_init(atm_cols, float(spec.co2_factor[c]), float(spec.rh_scale[c]))
+        rel_hum[c] = ci["rel_hum"]
+        if mode == "repwvl":
+            gas[c] = ci["vmr9"]
+        else:  # multipliers of the tabulated optical depths: tau is linear in the mixing ratio
+            gas[c, 0] = spec.co2_factor[c]
+            gas[c, 1] = spec.rh_scale[c]
+            gas[c, 2:] = 1.0
+    return dict(plevel=base["plevel"], player=base["player"], conv=base["conv"], Tlayer0=Tlayer0,
+                T_surface0=np.ascontiguousarray(spec.T_surface0, dtype=np.float64), gas=gas,
+                rel_hum=rel_hum, h2o_ref=base["vmr9"][0].copy())
+
+
+def synth_lbl_tables(n_nodes=131072, plevel=None, nlayer=20, seed=SEED, lam_lo=3000.0, lam_hi=100000.0):
+    """Seeded stand-in for lbl.{co2,h2o,o3,ch4,n2o}.asc (lbl.arts/README:5-9): wavelength nodes [nm]
+    log-spaced and strictly increasing, and per species a [n_nodes][nlayer] layer optical depth
+    tau_s[w][l] = A_s * (p_l/1000) * 10**g_s(w), g_s a sum of Lorentzian 'lines', log10(tau) kept in
+    [-8, 4.5] (the span of the repwvl optical depths).  Returns (wvl, [5 tables])."""
+    if plevel is None:
+        plevel = np.linspace(0.0, 1000.0, nlayer + 1)
+    player = 0.5 * (np.asarray(plevel[:-1]) + np.asarray(plevel[1:]))
+    wvl = np.exp(np.linspace(np.log(lam_lo), np.log(lam_hi), n_nodes))
+    wvl[0], wvl[-1] = lam_lo, lam_hi
+    assert np.all(np.diff(wvl) > 0)
+    x = np.linspace(0.0, 1.0, n_nodes)
+    amp = dict(co2=1.0, h2o=2.0, o3=0.05, ch4=0.02, n2o=0.02)  # H2O and CO2 dominate
+    centre = dict(co2=0.46, h2o=0.25, o3=0.33, ch4=0.27, n2o=0.14)  # band centre in log-wavelength
+    tabs = []
+    for s, name in enumerate(LBL_SPECIES):
+        rng = np.random.Generator(np.random.PCG64(seed + s))
+        nlines = 160
+        x0 = np.clip(rng.normal(centre[name], 0.12, nlines), 0.0, 1.0)
+        if name == "h2o":  # water absorbs across the whole thermal range
+            x0 = rng.uniform(0.0, 1.0, nlines)
+        width = 10.0 ** rng.uniform(-4.0, -2.2, nlines)
+        height = rng.uniform(0.5, 4.0, nlines)
+        g = np.full(n_nodes, -3.5)
+        for k in range(nlines):
+            g += height[k] / (1.0 + ((x - x0[k]) / width[k]) ** 2)
+        g += 0.35 * np.sin(2 * np.pi * (37 + 11 * s) * x)  # fine ripple so neighbouring nodes differ
+        logt = np.clip(g + np.log10(amp[name]), -8.0, 4.5)
+        tab = (10.0 ** logt)[:, None] * (player[None, :] / 1000.0)
+        tabs.append(np.ascontiguousarray(tab))
+    return wvl, tabs

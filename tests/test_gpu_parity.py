@@ -1,0 +1,234 @@
+"""GPU: the HIP path, called through the C ABI, against the CPU oracle on the same inputs.
+
+Tolerances (BASELINE.json north_star / SURVEY.md 8d): fluxes <= 1e-6 W/m^2 absolute, optical depths
+<= 1e-12 relative, temperatures <= 1e-6 K after the stated number of steps.  fp64 with a different
+summation order and a different exp() implementation lands around 1e-10; the asserts use a margin
+tighter than the contract so a regression shows early."""
+import os
+
+import numpy as np
+import pytest
+
+import helpers as H
+
+pytestmark = pytest.mark.gpu
+
+FLUX_TOL = 1e-6  # W/m^2, the contract
+FLUX_TIGHT = 2e-9
+TEMP_TOL = 1e-6  # K, the contract
+
+
+@pytest.fixture(scope="module")
+def pkg(rcm):
+    import torch
+    assert torch.cuda.is_available(), "these tests need the MI355X"
+    return rcm
+
+
+def _check_fluxes(g, o, tol=FLUX_TIGHT):
+    fg, fo = g.get_fluxes(), o.get_fluxes()
+    for k in ("E_down", "E_up", "dE"):
+        d = H.max_abs(fg[k], fo[k])
+        assert d <= tol, (k, d)
+    return max(H.max_abs(fg[k], fo[k]) for k in fg)
+
+
+def _check_state(g, o, tol=TEMP_TOL):
+    sg, so = g.get_state(), o.get_state()
+    assert H.max_abs(sg["Tlayer"], so["Tlayer"]) <= tol
+    assert H.max_abs(sg["T_surface"], so["T_surface"]) <= tol
+    np.testing.assert_allclose(sg["timestep"], so["timestep"], rtol=1e-9)
+    np.testing.assert_allclose(sg["time_h"], so["time_h"], rtol=2e-6)
+
+
+@pytest.mark.parametrize("table", ["Reduced10", "Reduced20", "Reduced100"])
+def test_repwvl_single_column_tau_fluxes_and_101_steps(pkg, olib, probe, table):
+    inp = H.make_inputs(pkg, "repwvl", 1, table=table, perturb=False)
+    g, o = H.gpu_ensemble(pkg, inp), H.oracle_ensemble(olib, inp)
+    # a5: optical depths of read_tau + cloud
+    tg, to = g.get_tau(0), o.get_tau(0)
+    assert tg.shape == to.shape == (inp["table"]["n_wvl"], 20)
+    np.testing.assert_allclose(tg, to, rtol=1e-12, atol=0)
+    # a1-a4, a6, a7 at step 0
+    g.step(1), o.step(1)
+    _check_fluxes(g, o)
+    _check_state(g, o, 1e-9)
+    # straight against the reference's recorded numbers too
+    want = probe[table].get("step0")
+    if want:
+        assert abs(g.get_fluxes()["E_up"][0, 0] - want["E_up_0"]) <= FLUX_TIGHT
+        assert abs(g.get_state()["timestep"][0] - want["timestep"]) <= 1e-6
+    # 100 more steps: adjustment, feedback, re-interpolated tau every step
+    g.step(100), o.step(100)
+    _check_state(g, o)
+    assert abs(g.get_state()["T_surface"][0] - probe[table]["after_101_steps"]["T_surface"]) <= TEMP_TOL
+    _check_fluxes(g, o, 1e-7)
+
+
+def test_repwvl_ragged_ensemble(pkg, olib):
+    # 37 columns: not a multiple of the 4 columns per block; CO2, RH and surface-T perturbed
+    inp = H.make_inputs(pkg, "repwvl", 37, table="Reduced100")
+    g, o = H.gpu_ensemble(pkg, inp), H.oracle_ensemble(olib, inp)
+    for c in (0, 17, 36):
+        np.testing.assert_allclose(g.get_tau(c), o.get_tau(c), rtol=1e-12, atol=0)
+    g.step(6), o.step(6)
+    _check_fluxes(g, o)
+    _check_state(g, o)
+    np.testing.assert_allclose(g.get_gas(), o.get_gas(), rtol=1e-12, atol=0)  # feedback rewrote H2O
+
+
+@pytest.mark.parametrize("n_nodes", [2, 65, 1000])
+def test_lbl_small_against_oracle(pkg, olib, n_nodes):
+    # lbl composition + band Planck (cplkavg) + sweep; 1000 nodes = 999 bands (ragged last row of lanes)
+    inp = H.make_inputs(pkg, "lbl", 5, n_nodes=n_nodes, atm="fpda.lbl.atm")
+    g, o = H.gpu_ensemble(pkg, inp), H.oracle_ensemble(olib, inp)
+    assert g.nspectral() == o.nspectral() == n_nodes - 1
+    np.testing.assert_allclose(g.get_tau(3), o.get_tau(3), rtol=1e-13, atol=0)
+    g.step(1), o.step(1)
+    _check_fluxes(g, o)
+    g.step(3), o.step(3)
+    _check_fluxes(g, o)
+    _check_state(g, o)
+    np.testing.assert_allclose(g.get_gas(), o.get_gas(), rtol=1e-12, atol=0)
+
+
+def test_lbl_wide_bands_take_the_series_branches(pkg, olib):
+    # 12 nodes over 3..100 um: (wnumhi-wnumlo)/wnumhi > 1e-2 -> power / exponential series of cplkavg
+    inp = H.make_inputs(pkg, "lbl", 2, n_nodes=12, atm="fpda.lbl.atm")
+    g, o = H.gpu_ensemble(pkg, inp), H.oracle_ensemble(olib, inp)
+    g.step(2), o.step(2)
+    _check_fluxes(g, o, 1e-8)
+    _check_state(g, o)
+
+
+def test_chunking_and_kernel_variants_agree(pkg, olib, monkeypatch):
+    inp = H.make_inputs(pkg, "lbl", 3, n_nodes=1500, atm="fpda.lbl.atm")
+    o = H.oracle_ensemble(olib, inp)
+    o.step(2)
+    fo = o.get_fluxes()
+    for expv, cube, chunks in ((0, 0, 1), (1, 0, 0), (0, 1, 5), (1, 1, 24), (1, 1, 3)):
+        monkeypatch.setenv("RCM_EXP_VARIANT", str(expv))
+        monkeypatch.setenv("RCM_CUBE", str(cube))
+        g = H.gpu_ensemble(pkg, inp)
+        g.set_spectral_chunks(chunks)
+        g.step(2)
+        fg = g.get_fluxes()
+        for k in fo:
+            assert H.max_abs(fg[k], fo[k]) <= FLUX_TIGHT, (expv, cube, chunks, k)
+        g.close()
+
+
+def test_first_step_uses_pre_adjustment_profile_for_tau(pkg, olib):
+    # main.cpp:500 precedes the loop: an unstable initial profile is interpolated BEFORE the sort
+    inp = H.make_inputs(pkg, "repwvl", 2, table="Reduced20", perturb=False)
+    inp["cols"]["Tlayer0"][:, 15] += 25.0  # theta no longer monotone -> the sort reorders layers
+    g, o = H.gpu_ensemble(pkg, inp), H.oracle_ensemble(olib, inp)
+    g.step(1), o.step(1)
+    _check_fluxes(g, o)
+    g.step(2), o.step(2)
+    _check_state(g, o)
+
+
+def test_profile_rows_match_reference_output_txt(pkg, golden):
+    inp = H.make_inputs(pkg, "repwvl", 1, table="Reduced10", perturb=False)
+    g = H.gpu_ensemble(pkg, inp)
+    T, th, tm = g.get_profile(0)
+    rows = [f"{i},{inp['cols']['player'][i]:f},{T[i]:f},{th[i]:f},{tm:f}" for i in range(20)]
+    ref = open(os.path.join(golden, "reference_output.txt")).read().splitlines()
+    assert rows == ref[7:27]  # output.txt:8-27
+
+
+def test_cloud_can_be_disabled_and_moved(pkg, olib):
+    inp = H.make_inputs(pkg, "repwvl", 3, table="Reduced10")
+    for layer, tau in ((-1, 0.0), (5, 0.3)):
+        inp["cloud_layer"], inp["cloud_tau"] = layer, tau
+        g, o = H.gpu_ensemble(pkg, inp), H.oracle_ensemble(olib, inp)
+        np.testing.assert_allclose(g.get_tau(1), o.get_tau(1), rtol=1e-12, atol=0)
+        g.step(2), o.step(2)
+        _check_fluxes(g, o)
+
+
+def test_error_behaviour(pkg):
+    with pytest.raises(pkg.RcmError) as e:
+        pkg.Ensemble(4, nlayer=19)
+    assert e.value.code == -1
+    with pytest.raises(pkg.RcmError) as e:
+        pkg.Ensemble(0)
+    assert e.value.code == -1
+    g = pkg.Ensemble(2)
+    with pytest.raises(pkg.RcmError) as e:
+        g.step(1)  # nothing set
+    assert e.value.code == -2
+    wvl = np.array([5000.0, 4000.0, 6000.0])  # not increasing: cplkavg.cpp:144 would exit(1)
+    with pytest.raises(pkg.RcmError) as e:
+        g.set_lbl_tables(wvl, [np.ones((3, 20))] * 5, np.ones(20))
+    assert e.value.code == -1
+
+
+def test_pack_state_into_a_torch_tensor(pkg, olib):
+    import torch
+    inp = H.make_inputs(pkg, "repwvl", 9, table="Reduced10")
+    g = H.gpu_ensemble(pkg, inp, stream=torch.cuda.current_stream().cuda_stream)
+    g.step(2)
+    buf = torch.empty((9, 21), dtype=torch.float64, device="cuda")
+    g.pack_state(buf.data_ptr())
+    torch.cuda.synchronize()
+    s = g.get_state()
+    np.testing.assert_array_equal(buf[:, :20].cpu().numpy(), s["Tlayer"])
+    np.testing.assert_array_equal(buf[:, 20].cpu().numpy(), s["T_surface"])
+
+
+# ---- full-size spectra: properties that need no oracle run --------------------------------------
+@pytest.fixture(scope="module")
+def big(pkg):
+    inp = H.make_inputs(pkg, "lbl", 8, n_nodes=131072, atm="fpda.lbl.atm")
+    return inp
+
+
+def test_full_spectrum_transparent_atmosphere_passes_surface_emission(pkg, olib, big):
+    # no absorber, no cloud: E_down = 0 and E_up = pi * sum_b cplkavg(b, T_surface) at every level
+    inp = dict(big)
+    inp["cols"] = dict(big["cols"])
+    inp["cols"]["gas"] = np.zeros_like(big["cols"]["gas"])
+    inp["cloud_layer"], inp["cloud_tau"] = -1, 0.0
+    g = H.gpu_ensemble(pkg, inp)
+    g.step(1)
+    f = g.get_fluxes()
+    assert np.all(f["E_down"] == 0.0)
+    ts = big["cols"]["T_surface0"]
+    want = np.array([np.pi * sum(olib.orc_cplkavg(big["wvl"][b], big["wvl"][b + 1], t)
+                                 for b in range(0, 131071, 1)) for t in ts[:2]])
+    for c in range(2):
+        assert np.all(np.abs(f["E_up"][c] - want[c]) <= 1e-7), (f["E_up"][c, 0], want[c])
+
+
+def test_full_spectrum_isothermal_column(pkg, big):
+    # T_layer = T_surface: L_up = B on every path, so E_up is level-independent and E_down grows downward
+    inp = dict(big)
+    inp["cols"] = dict(big["cols"])
+    inp["cols"]["Tlayer0"] = np.full_like(big["cols"]["Tlayer0"], 260.0)
+    inp["cols"]["T_surface0"] = np.full_like(big["cols"]["T_surface0"], 260.0)
+    g = H.gpu_ensemble(pkg, inp)
+    g.step(1)
+    f = g.get_fluxes()
+    assert np.max(np.abs(f["E_up"] - f["E_up"][:, -1:])) <= 1e-9
+    assert np.all(np.diff(f["E_down"], axis=1) >= 0)
+    assert np.all(f["E_down"] <= f["E_up"] + 1e-9)
+
+
+def test_full_spectrum_chunking_invariance_and_replica_identity(pkg, big):
+    inp = dict(big)
+    inp["cols"] = {k: (np.repeat(v[:1], 8, axis=0) if getattr(v, "shape", (0,))[0] == 8 else v)
+                   for k, v in big["cols"].items()}  # 8 identical columns
+    res = []
+    for chunks in (0, 7):
+        g = H.gpu_ensemble(pkg, inp)
+        g.set_spectral_chunks(chunks)
+        g.step(2)
+        res.append((g.get_fluxes(), g.get_state()))
+        g.close()
+    (f0, s0), (f1, s1) = res
+    for k in f0:
+        assert np.all(f0[k] == f0[k][:1]), "identical columns must give bit-identical results"
+        assert H.max_abs(f0[k], f1[k]) <= FLUX_TIGHT
+    assert H.max_abs(s0["Tlayer"], s1["Tlayer"]) <= 1e-9

@@ -1,0 +1,248 @@
+"""CPU: the oracle against every fixture the reference holds for this path, and the
+host-side C-ABI functions against the oracle.  No GPU needed."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+import oracle_lib as ol
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _single_column_oracle(olib, golden, table, co2=1.0):
+    atm, nc = ol.atm_load(olib, os.path.join(golden, "test.atm"))
+    assert atm.shape == (9, 21) and nc == 9
+    ci = ol.column_init(olib, atm, co2, 1.0)
+    sol = np.zeros(7)
+    olib.orc_default_solar(ol._p(sol))
+    e = ol.OracleEnsemble(olib, 1)
+    e.set_grid(ci["plevel"])
+    e.set_forcing(sol[6])
+    e.set_repwvl_tables(ol.read_rtab(os.path.join(golden, f"{table}Forcing.rtab")))
+    e.set_columns(ci["Tlayer"][None], np.array([288.2]), ci["vmr9"][None], ci["rel_hum"][None])
+    return e
+
+
+def test_solar_matches_reference_probe(olib, probe):
+    sol = np.zeros(7)
+    olib.orc_default_solar(ol._p(sol))
+    want = probe["solar_tau_s_2.0"]
+    for k, name in enumerate(("r_dir", "s_dir", "t_dir", "r", "t", "r_total", "solar_irr")):
+        assert sol[k] == want[name], name  # bit-identical
+
+
+def test_solar_banners_of_reference_output_txt(olib, probe):
+    # output.txt:3-6 and :30-33 (older tau_s values, same functions)
+    for b in probe["output_txt_banners"]:
+        sol = np.zeros(7)
+        olib.orc_solar_setup(b["tau_s"], b["mu_s"], 20, 0.85, 0.12, 0.5, 1361.0, ol._p(sol))
+        assert f"{sol[5]:f}" == f"{b['albedo']:f}"
+        assert f"{sol[0]:f}" == f"{b['rdir']:f}"
+        assert f"{sol[1]:f}" == f"{b['sdir']:f}"
+        assert f"{sol[2]:f}" == f"{b['tdir']:f}"
+        assert f"{sol[6]:f}" == f"{b['solar']:f}"
+
+
+def test_t0_rows_of_reference_output_txt(olib, golden):
+    # output.txt:8-27: atm loader -> layer means -> theta -> sort -> back, at t = 0
+    e = _single_column_oracle(olib, golden, "Reduced10")
+    T, th, tm = e.get_profile(0)
+    atm, _ = ol.atm_load(olib, os.path.join(golden, "test.atm"))
+    player = ol.column_init(olib, atm)["player"]
+    rows = [f"{i},{player[i]:f},{T[i]:f},{th[i]:f},{tm:f}" for i in range(20)]
+    ref = open(os.path.join(golden, "reference_output.txt")).read().splitlines()
+    assert rows == ref[7:27]
+    assert rows == ref[34:54]  # second recorded run, identical rows
+
+
+@pytest.mark.parametrize("table", ["Reduced100", "Reduced10"])
+def test_step0_fluxes_bit_identical_to_reference(olib, golden, probe, table):
+    e = _single_column_oracle(olib, golden, table)
+    e.step(1)
+    f, s = e.get_fluxes(), e.get_state()
+    want = probe[table]["step0"]
+    assert f["E_up"][0, 0] == want["E_up_0"]
+    assert f["E_down"][0, 20] == want["E_down_20"]
+    assert f["E_up"][0, 20] == want["E_up_20"]
+    assert s["timestep"][0] == want["timestep"]
+    if "dE_0" in want:
+        assert f["dE"][0, 0] == want["dE_0"]
+        assert f["dE"][0, 17] == want["dE_17"]
+        assert f["dE"][0, 19] == want["dE_19"]
+        assert s["T_surface"][0] == want["T_surface_after"]
+
+
+def test_step1_and_co2_doubling(olib, golden, probe):
+    e = _single_column_oracle(olib, golden, "Reduced100")
+    e.step(2)
+    assert e.get_fluxes()["E_up"][0, 0] == probe["Reduced100"]["step1"]["E_up_0"]
+    assert e.get_state()["timestep"][0] == probe["Reduced100"]["step1"]["timestep"]
+    e2 = _single_column_oracle(olib, golden, "Reduced100", co2=2.0)
+    e2.step(1)
+    f = e2.get_fluxes()
+    assert f["E_up"][0, 0] == probe["Reduced100"]["co2x2_step0"]["E_up_0"]
+    assert f["E_down"][0, 20] == probe["Reduced100"]["co2x2_step0"]["E_down_20"]
+
+
+@pytest.mark.parametrize("table", ["Reduced100", "Reduced20", "Reduced10"])
+def test_101_steps_bit_identical_to_reference(olib, golden, probe, table):
+    e = _single_column_oracle(olib, golden, table)
+    e.step(101)  # i = 0..100 inclusive, main.cpp:531 with n_steps = 100
+    s = e.get_state()
+    want = probe[table]["after_101_steps"]
+    assert s["T_surface"][0] == want["T_surface"]
+    assert f"{s['time_h'][0]:.6f}"[:9] == f"{want['time_h']:.6f}"[:9]
+
+
+def test_tau_samples(olib, golden, probe):
+    e = _single_column_oracle(olib, golden, "Reduced100")
+    tau = e.get_tau(0)
+    w = probe["Reduced100"]["tau_step0"]
+    assert f"{tau[0, 0]:.6g}" == f"{w['tau_0_0']:.6g}"
+    assert f"{tau[0, 17]:.6g}" == f"{w['tau_0_17']:.6g}"
+    assert f"{tau[99, 19]:.6g}" == f"{w['tau_99_19']:.6g}"
+
+
+def test_cplkavg_known_answers(olib, probe):
+    for lo, hi, t, want in probe["cplkavg_kat"]:
+        got = olib.orc_cplkavg(lo, hi, t)
+        assert got == want, (lo, hi, t, got, want)
+
+
+def _ref_lib(name):
+    p = os.path.join(ROOT, "oracle", "_ref", name)
+    if not os.path.exists(p):
+        pytest.skip(f"{name} not built (reference tree absent at build time)")
+    return C.CDLL(p)
+
+
+def test_cplkavg_against_compiled_reference(olib):
+    ref = _ref_lib("libref_cplkavg.so")
+    f = getattr(ref, "_Z7cplkavgddd")  # double cplkavg(double,double,double), cplkavg.h:7
+    f.restype = C.c_double
+    f.argtypes = [C.c_double] * 3
+    rng = np.random.default_rng(7)
+    n = 0
+    for _ in range(4000):
+        lo = float(np.exp(rng.uniform(np.log(300.0), np.log(2e5))))
+        kind = rng.integers(0, 3)
+        hi = lo * (1 + 10 ** rng.uniform(-6, -2.2)) if kind == 0 else lo * rng.uniform(1.011, 50.0)
+        t = float(rng.uniform(150.0, 350.0)) if kind < 2 else float(10 ** rng.uniform(0.5, 4))
+        assert olib.orc_cplkavg(lo, hi, t) == f(lo, hi, t), (lo, hi, t)
+        n += 1
+    assert n == 4000
+
+
+def test_product_ascii_loader_against_compiled_reference(rcm, tmp_path):
+    ref = _ref_lib("libref_ascii.so")
+    dpp = C.POINTER(C.POINTER(C.c_double))
+    ref.ASCII_file2xy2D.argtypes = [C.c_char_p, C.POINTER(C.c_int), C.POINTER(C.c_int),
+                                    C.POINTER(C.POINTER(C.c_double)), C.POINTER(dpp)]
+    rng = np.random.default_rng(3)
+    cases = {}
+    body = "% lbl.xxx.asc\n# second comment style\n\n"
+    for r in range(37):
+        row = [3000.0 + 17.25 * r] + list(10 ** rng.uniform(-8, 4, 20))
+        body += ("\t" if r % 5 == 0 else " ") + "  ".join(f"{v:.9e}" for v in row)
+        body += "   % trailing comment 1 2 3\n" if r % 7 == 0 else "\n"
+        if r % 11 == 0:
+            body += "   \n"
+    cases["ok.asc"] = body
+    cases["ragged.asc"] = "1 2 3\n4 5\n"
+    cases["words.asc"] = "1 abc 3\n4 5 nan\n"
+    cases["empty.asc"] = "% nothing\n\n"
+    cases["onecol.asc"] = "1\n2\n3\n"
+    for name, text in cases.items():
+        p = tmp_path / name
+        p.write_text(text)
+        nx, ny = C.c_int(0), C.c_int(0)
+        x, y = C.POINTER(C.c_double)(), dpp()
+        st_ref = ref.ASCII_file2xy2D(str(p).encode(), C.byref(nx), C.byref(ny), C.byref(x), C.byref(y))
+        st, xs, ys = rcm.ascii_file2xy2D(str(p))
+        assert st == st_ref, name
+        if st == 0:
+            assert xs.shape == (nx.value,) and ys.shape == (nx.value, ny.value), name
+            xr = np.array([x[i] for i in range(nx.value)])
+            yr = np.array([[y[i][j] for j in range(ny.value)] for i in range(nx.value)]).reshape(nx.value, ny.value)
+            np.testing.assert_array_equal(xs, xr)
+            np.testing.assert_array_equal(ys, yr)
+    st, _, _ = rcm.ascii_file2xy2D(str(tmp_path / "missing.asc"))
+    nx, ny = C.c_int(0), C.c_int(0)
+    x, y = C.POINTER(C.c_double)(), dpp()
+    assert st == ref.ASCII_file2xy2D(str(tmp_path / "missing.asc").encode(), C.byref(nx), C.byref(ny),
+                                     C.byref(x), C.byref(y)) == -1
+
+
+def test_host_abi_matches_oracle(rcm, olib, golden):
+    """rcm_atm_load / rcm_column_init / rcm_solar_setup / rcm_rtab_load (host C++) == oracle (C)."""
+    for atm_name in ("test.atm", "fpda.lbl.atm"):
+        a_p, nc_p = rcm.atm_load(os.path.join(golden, atm_name))
+        a_o, nc_o = ol.atm_load(olib, os.path.join(golden, atm_name))
+        assert nc_p == nc_o
+        np.testing.assert_array_equal(a_p, a_o)
+        for co2, rh in ((1.0, 1.0), (2.0, 1.0), (0.5, 1.07)):
+            p, o = rcm.column_init(a_p, co2, rh), ol.column_init(olib, a_o, co2, rh)
+            for k in o:
+                np.testing.assert_array_equal(p[k], o[k], err_msg=k)
+    sol = np.zeros(7)
+    olib.orc_default_solar(ol._p(sol))
+    assert list(rcm.default_solar().values()) == sol.tolist()
+    t_p = rcm.read_rtab(os.path.join(golden, "Reduced10Forcing.rtab"))
+    t_o = ol.read_rtab(os.path.join(golden, "Reduced10Forcing.rtab"))
+    for k in t_o:
+        np.testing.assert_array_equal(t_p[k], t_o[k], err_msg=k)
+
+
+def test_fpda_and_test_atm_describe_the_same_column(rcm, golden):
+    a, na = rcm.atm_load(os.path.join(golden, "test.atm"))
+    b, nb = rcm.atm_load(os.path.join(golden, "fpda.lbl.atm"))
+    assert (na, nb) == (9, 6)
+    np.testing.assert_array_equal(a, b)  # 400/1.7/0.315 ppm defaults, lbl.arts/README:14-17
+
+
+def test_library_exports_every_declared_symbol(rcm):
+    hdr = open(os.path.join(ROOT, "include", "rcm.h")).read()
+    names = set(re.findall(r"\b(rcm_[a-z0-9_A-Z]+)\s*\(", hdr))
+    assert len(names) >= 30
+    L = rcm.lib()
+    for n in sorted(names):
+        assert hasattr(L, n), f"{n} declared in include/rcm.h but not exported"
+    assert L.rcm_abi_version() == 1
+
+
+def test_no_gpu_means_loud_failure_not_fallback(rcm):
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    with pytest.raises(rcm.RcmError) as ei:
+        rcm.Ensemble(4)
+    assert ei.value.code == -3  # RCM_ERR_HIP
+
+
+def test_output_writers_reproduce_reference_formats(rcm, golden, tmp_path):
+    """rcm_write_banner / rcm_write_profile against output.txt:2-27 (tau_s = 2.07672 run)."""
+    libc = C.CDLL(None)
+    libc.fopen.restype = C.c_void_p
+    libc.fopen.argtypes = [C.c_char_p, C.c_char_p]
+    libc.fclose.argtypes = [C.c_void_p]
+    out = tmp_path / "output.txt"
+    f = libc.fopen(str(out).encode(), b"a")
+    sol = rcm.solar_setup(2.07672, 0.5)
+    arr = np.array(list(sol.values()))
+    L = rcm.lib()
+    assert L.rcm_write_banner(f, 2.07672, 0.5, arr.ctypes.data_as(C.POINTER(C.c_double))) == 0
+    atm, _ = rcm.atm_load(os.path.join(golden, "test.atm"))
+    ci = rcm.column_init(atm)
+    theta = ci["Tlayer"] * ci["conv"]
+    dp = C.POINTER(C.c_double)
+    assert L.rcm_write_profile(f, 20, ci["player"].ctypes.data_as(dp), ci["Tlayer"].ctypes.data_as(dp),
+                               theta.ctypes.data_as(dp), C.c_float(0.0)) == 0
+    libc.fclose(f)
+    got = out.read_text().splitlines()
+    ref = open(os.path.join(golden, "reference_output.txt")).read().splitlines()
+    # the recorded run printed tau_s with %2.5f (older revision); the current source prints %2.3f (main.cpp:516)
+    assert got[2] == ref[2].replace("2.07672", "2.077")
+    assert got[0:2] == ref[0:2] and got[3:27] == ref[3:27]
