@@ -5,7 +5,7 @@ import os
 import numpy as np
 
 PKG = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(PKG, "librcm_hip.so")
+LIB_PATH = os.environ.get("RCM_LIB_PATH") or os.path.join(PKG, "librcm_hip.so")  # override: A/B builds only
 
 _dp = C.POINTER(C.c_double)
 _fp = C.POINTER(C.c_float)

@@ -35,16 +35,32 @@ __device__ __forceinline__ double exp_poly10(double x) {
   for (int i = 9; i >= 0; --i) p = fma(p, r, kExpPoly10[i]);
   // 2^k: add k to the biased exponent (bits 52..62 = bits 20..30 of the high word)
   const int k = __double2loint(z);
-  const int hi = __double2hiint(p) + (k << 20);
+  const int hi = __double2hiint(p) + (int)((unsigned)k << 20);
   return __hiloint2double(hi, __double2loint(p));
 }
 
-template <int EXPV>
-__device__ __forceinline__ double exp_t(double x) {
-  if constexpr (EXPV == 0)
-    return exp(x);
-  else
-    return exp_poly10(x);
+// Transmission t = exp(-tau * s) with the per-angle constants a1 = -s*log2(e), a2 = -s.
+// tau must already be clamped to [kTauMin, kTauMax] (once per band-layer, clamp_tau) so that
+// |k| < 2^31; k < -1022 is pinned there by an integer max (t ~ 1e-308 stands in for 0).
+constexpr double kTauMin = -10.0;  // exp(+10*60) is still finite
+constexpr double kTauMax = 1.0e7;  // exp(-1e7) == 0 for every angle
+
+__device__ __forceinline__ double clamp_tau(double tau) { return fmin(fmax(tau, kTauMin), kTauMax); }
+
+__device__ __forceinline__ double exp_trans(double tau, double a1, double a2) {
+  constexpr double kLn2Hi = 0x1.62e42fefa39efp-1;
+  constexpr double kLn2Lo = 0x1.abc9e3b39803fp-56;
+  constexpr double kMagic = 0x1.8p+52;
+  const double z = fma(tau, a1, kMagic);
+  const double kf = z - kMagic;
+  double r = fma(kf, -kLn2Hi, tau * a2);
+  r = fma(kf, -kLn2Lo, r);
+  double p = kExpPoly10[10];
+#pragma unroll
+  for (int i = 9; i >= 0; --i) p = fma(p, r, kExpPoly10[i]);
+  const int k = max(__double2loint(z), -1022);
+  const int hi = __double2hiint(p) + (int)((unsigned)k << 20);
+  return __hiloint2double(hi, __double2loint(p));
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -68,12 +84,13 @@ __device__ __forceinline__ double planck_mono(double pnum, double lam5, double l
 // ---------------------------------------------------------------------------------------------
 __device__ __forceinline__ double plkf(double x) { return x * x * x / (exp(x) - 1.); }  // :109-113
 
+constexpr double kConc = 0x1.3b5ef8356c19dp-3;  // 15/pi^4 = 15./pow(M_PI,4.) bit for bit, cplkavg.cpp:135
+
 __device__ inline double cplkavg_dev(double wnumlo, double wnumhi, double t, double tpre) {
   constexpr double A1 = 1. / 3., A2 = -1. / 8., A3 = 1. / 60., A4 = -1. / 5040., A5 = 1. / 272160.,
                    A6 = -1. / 13305600.;
   constexpr double C2 = 1.438786, VCUT = 1.5;
   constexpr double kVmax = 0x1.62e42fefa39efp+9;                  // log(DBL_MAX), :133
-  constexpr double kConc = 15. / (M_PI * M_PI * M_PI * M_PI);     // :135 (pow(M_PI,4.) differs by <= 1 ulp)
   constexpr double kEps = 2.2204460492503131e-16;                 // DBL_EPSILON
   if (t < 1.e-4) return 0.;                                       // :148
   const double v0 = C2 * wnumlo / t, v1 = C2 * wnumhi / t;        // :152-153
@@ -124,6 +141,42 @@ __device__ inline double cplkavg_dev(double wnumlo, double wnumhi, double t, dou
   else
     ans = d[0] - d[1];
   return ans * tpre;                                              // :237
+}
+
+// Narrow-band fast path of cplkavg.  When the band is so narrow that hh = v1 - v0 < kHhFast, the
+// reference's Simpson iteration (cplkavg.cpp:159-181) converges at n = 2 with a truncation error
+// of hh^4/2880 * (f4/f) <= 6e-15 (f4 = fourth derivative), i.e. it returns the exact integral to
+// rounding; the midpoint rule with the curvature term, hh * (f(xm) + hh^2/24 * f2(xm)) with
+// f = x^3/(e^x - 1) and f2 its second derivative, has error hh^4/1920 * (f4/f) and is the same
+// number to <= 4e-15 relative (checked against the reference's compiled cplkavg.cpp in tests/) for
+// one exp and one reciprocal instead of six of each.  v0, v1 are formed as in cplkavg.cpp:152-153
+// (C2*wnum/t): the product with rT = 1/t plus one residual FMA step is the correctly rounded
+// quotient, so hh carries the reference's own rounding.  Returns false when the fast path does not
+// apply (the caller then runs cplkavg_dev).
+constexpr double kHhFast = 2.0e-3;
+
+__device__ __forceinline__ double div_by_t(double c, double t, double rT) {
+  const double q = c * rT;
+  return fma(fma(-q, t, c), rT, q);
+}
+
+__device__ __forceinline__ bool cplkavg_fast(double c2lo, double c2hi, double t, double rT,
+                                             double pc, double *out) {
+  const double v0 = div_by_t(c2lo, t, rT), v1 = div_by_t(c2hi, t, rT);
+  const double hh = v1 - v0;
+  if (!(hh < kHhFast && v0 > 2.2204460492503131e-16 && v1 < 700.0 && t >= 1.e-4)) return false;
+  const double xm = 0.5 * (v0 + v1);
+  const double d = exp_poly10(xm) - 1.0;
+  double g = __builtin_amdgcn_rcp(d);  // ~2^-26 relative; two Newton steps reach full precision
+  g = fma(fma(-d, g, 1.0), g, g);
+  g = fma(fma(-d, g, 1.0), g, g);
+  const double g1 = -g * (1.0 + g);          // dg/dx
+  const double g2 = -g1 * fma(2.0, g, 1.0);  // d2g/dx2
+  const double x2 = xm * xm, x3 = x2 * xm;
+  const double f = x3 * g;
+  const double f2 = fma(x3, g2, fma(6.0 * x2, g1, 6.0 * xm * g));
+  *out = pc * (hh * fma(hh * hh * (1.0 / 24.0), f2, f));
+  return true;
 }
 
 // Magnus saturation vapour pressure [hPa]: main.cpp:277-279

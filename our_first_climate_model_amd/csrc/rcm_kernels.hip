@@ -25,6 +25,19 @@ constexpr int NL = 20;       // layers   (main.cpp:78); kernels are specialised 
 constexpr int NLEV = NL + 1; // levels   (main.cpp:79)
 constexpr int PSTRIDE = 2 * NLEV;  // one partial record: E_down[21], E_up[21]
 constexpr int WPB = 4;       // waves per block = columns per block (one per SIMD)
+// Tuning knobs (compile time; tools/build_variants.py A/Bs them on the GPU).
+#ifndef RCM_LB
+#define RCM_LB 1  // waves per SIMD the lbl RT kernel is register-allocated for (1: spills go to AGPRs, not scratch)
+#endif
+#ifndef RCM_B_LDS
+#define RCM_B_LDS 0  // 1: the sweeps re-read the Planck column from LDS; 0: it is hoisted into 42 VGPRs
+#endif
+#ifndef RCM_SCHED4
+#define RCM_SCHED4 0  // scheduling barrier after every 4th transmission exp
+#endif
+#ifndef RCM_PLK_UNROLL
+#define RCM_PLK_UNROLL 1  // independent band-Planck evaluations in flight
+#endif
 
 enum { MODE_NONE = -1, MODE_REPWVL = 0, MODE_LBL = 1 };
 
@@ -55,20 +68,49 @@ struct Dev {
 // t[l] = exp(-tau_l/mu).  The reference's L = (1-alpha)*L + alpha*B with alpha = 1-t is
 // evaluated as B + t*(L-B).
 // ---------------------------------------------------------------------------------------------
-__device__ __forceinline__ void sweep(const double (&t)[NL], const double (&B)[NL], double Bs,
-                                      double cw, double (&Ed)[NLEV], double (&Eu)[NLEV]) {
+// B = the lane's Planck column in LDS (B[l][0] for layer l, B[NL][0] for the surface): the level
+// grid lives in LDS, the 41 flux accumulators and the transmissions in VGPRs.
+__device__ __forceinline__ void sweep(const double (&t)[NL], const double (*B)[64], double cw,
+                                      double (&Ed)[NLEV], double (&Eu)[NLEV]) {
+  // Compiler fence: B must be re-read from LDS in every sweep.  Without it the loads are hoisted
+  // out of the angle loop into 42 VGPRs and the kernel spills.
+#if RCM_B_LDS
+  asm volatile("" ::: "memory");
+#endif
   double L = 0.0;  // main.cpp:300
 #pragma unroll
   for (int l = 0; l < NL; ++l) {  // main.cpp:306-309
-    L = fma(t[l], L - B[l], B[l]);
+    const double Bl = B[l][0];
+    L = fma(t[l], L - Bl, Bl);
     Ed[l + 1] = fma(cw, L, Ed[l + 1]);
   }
-  double Lu = Bs;                 // main.cpp:301
+  double Lu = B[NL][0];           // main.cpp:301
   Eu[NL] = fma(cw, Lu, Eu[NL]);   // main.cpp:302
 #pragma unroll
   for (int l = NL - 1; l >= 0; --l) {  // main.cpp:311-314
-    Lu = fma(t[l], Lu - B[l], B[l]);
+    const double Bl = B[l][0];
+    Lu = fma(t[l], Lu - Bl, Bl);
     Eu[l] = fma(cw, Lu, Eu[l]);
+  }
+}
+
+// t_l = exp(-tau_l/mu) for one angle (main.cpp:207-212).  EXPV 1 expects clamp_tau()'d optical depths.
+template <int EXPV>
+__device__ __forceinline__ void transmissions(const double (&tau)[NL], double inv_mu, double (&t)[NL]) {
+  if constexpr (EXPV == 0) {
+#pragma unroll
+    for (int l = 0; l < NL; ++l) t[l] = exp(-tau[l] * inv_mu);
+  } else {
+    const double a2 = -inv_mu, a1 = a2 * 0x1.71547652b82fep+0;
+#pragma unroll
+    for (int l = 0; l < NL; ++l) {
+      t[l] = exp_trans(tau[l], a1, a2);
+      // Four independent exp chains are enough to cover the fp64 latency; letting the scheduler
+      // interleave all twenty inflates the live temporaries past 256 VGPRs and spills tau to scratch.
+#if RCM_SCHED4
+      if ((l & 3) == 3) __builtin_amdgcn_sched_barrier(0);
+#endif
+    }
   }
 }
 
@@ -77,27 +119,25 @@ __device__ __forceinline__ void sweep(const double (&t)[NL], const double (&B)[N
 // rest follow by two multiplications per layer (20 instead of 30 exp per layer at nangle 30).
 template <int EXPV, int CUBE>
 __device__ __forceinline__ void all_angles(const Dev &d, const double (&tau)[NL],
-                                           const double (&B)[NL], double Bs, double (&Ed)[NLEV],
+                                           const double (*B)[64], double (&Ed)[NLEV],
                                            double (&Eu)[NLEV]) {
   const int na = d.nangle;
   if constexpr (!CUBE) {
     for (int i = 0; i < na; ++i) {
       const double inv_mu = d.ang[i], cw = d.ang[na + i];
       double t[NL];
-#pragma unroll
-      for (int l = 0; l < NL; ++l) t[l] = exp_t<EXPV>(-tau[l] * inv_mu);  // main.cpp:209
-      sweep(t, B, Bs, cw, Ed, Eu);
+      transmissions<EXPV>(tau, inv_mu, t);  // main.cpp:209
+      sweep(t, B, cw, Ed, Eu);
     }
   } else {
     const int N = 2 * na - 1;
     for (int n = N; 3 * n > N; n -= 2) {
       const double inv_mu = d.ang[(n - 1) >> 1];
       double t[NL];
-#pragma unroll
-      for (int l = 0; l < NL; ++l) t[l] = exp_t<EXPV>(-tau[l] * inv_mu);
+      transmissions<EXPV>(tau, inv_mu, t);
       int m = n;
       for (;;) {
-        sweep(t, B, Bs, d.ang[na + ((m - 1) >> 1)], Ed, Eu);
+        sweep(t, B, d.ang[na + ((m - 1) >> 1)], Ed, Eu);
         if (m % 3 != 0) break;
         m /= 3;
 #pragma unroll
@@ -194,9 +234,9 @@ __device__ __forceinline__ double repwvl_tau_layer(const Dev &d, const RepwvlLds
 // blocks) work on the SAME spectral chunk of different columns, so a table tile is fetched
 // from HBM once and then served from L2 to every column.
 // ---------------------------------------------------------------------------------------------
-template <int EXPV, int CUBE>
-__global__ __launch_bounds__(64 * WPB, 2) void k_rt_lbl(Dev d) {
-  __shared__ double s_col[WPB][192];
+template <int EXPV, int CUBE, int PLK>
+__global__ __launch_bounds__(64 * WPB, RCM_LB) void k_rt_lbl(Dev d) {
+  __shared__ double s_col[WPB][200];
   __shared__ double s_stage[WPB][NLEV][64];  // per-lane scratch column, indexable at run time
   const int lane = threadIdx.x & 63;
   const int wib = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -206,13 +246,21 @@ __global__ __launch_bounds__(64 * WPB, 2) void k_rt_lbl(Dev d) {
   const bool valid = colraw < d.ncol;
   const int col = valid ? colraw : d.ncol - 1;
   double(*st)[64] = s_stage[wib];
-  // LDS: [0..19] Tlayer, [20] T_surface, [21..41] sigdpi*T^4, [48..147] gas multipliers [5][20]
+  // LDS: [0..19] Tlayer, [20] T_surface, [21..41] sigdpi*T^4, [48..147] gas multipliers [5][20],
+  //      [150..170] sigdpi*T^4*conc, [171..191] 1/T
   double *sc = s_col[wib];
   if (lane < NL) sc[lane] = d.T[(size_t)col * NL + lane];
   if (lane == NL) sc[NL] = d.Tsfc[col];
   for (int i = lane; i < RCM_NSPEC_LBL * NL; i += 64) sc[48 + i] = d.gas[(size_t)col * RCM_NSPEC_LBL * NL + i];
   __syncthreads();
-  if (lane <= NL) sc[NLEV + lane] = d.sigdpi * pow(sc[lane], 4.0);  // cplkavg.cpp:181,237
+  // cplkavg.cpp:181,237: sigdpi * pow(t,4) (* conc on the Simpson path), once per column-level
+  if (lane <= NL) {
+    const double t = sc[lane];
+    const double tp = d.sigdpi * pow(t, 4.0);
+    sc[NLEV + lane] = tp;
+    sc[150 + lane] = tp * kConc;
+    sc[171 + lane] = 1.0 / t;
+  }
   __syncthreads();
 
   double Ed[NLEV], Eu[NLEV];
@@ -222,19 +270,23 @@ __global__ __launch_bounds__(64 * WPB, 2) void k_rt_lbl(Dev d) {
   const long b0 = (long)chunk * d.chunk_len;
   const long b1 = min(b0 + (long)d.chunk_len, (long)d.nspec);
   for (long b = b0 + lane; b < b1; b += 64) {  // main.cpp:329, lanes over spectral points
-    double tau[NL], B[NL];
+    double tau[NL];
 #pragma unroll 4
     for (int l = 0; l < NL; ++l) st[l][lane] = lbl_tau_layer(d, sc + 48, b, l);
 #pragma unroll
-    for (int l = 0; l < NL; ++l) tau[l] = st[l][lane];
+    for (int l = 0; l < NL; ++l) tau[l] = EXPV ? clamp_tau(st[l][lane]) : st[l][lane];
     const double wnumhi = 1.0E7 / d.lbl_wvl[b];      // cplkavg.cpp:141
     const double wnumlo = 1.0E7 / d.lbl_wvl[b + 1];  // cplkavg.cpp:142
-#pragma unroll 1
-    for (int l = 0; l <= NL; ++l) st[l][lane] = cplkavg_dev(wnumlo, wnumhi, sc[l], sc[NLEV + l]);
-#pragma unroll
-    for (int l = 0; l < NL; ++l) B[l] = st[l][lane];
-    const double Bs = st[NL][lane];
-    all_angles<EXPV, CUBE>(d, tau, B, Bs, Ed, Eu);
+    const double c2lo = 1.438786 * wnumlo, c2hi = 1.438786 * wnumhi;  // cplkavg.cpp:152-153
+    const bool narrow = PLK && (wnumhi - wnumlo) / wnumhi < 1.e-2;     // cplkavg.cpp:155
+#pragma unroll RCM_PLK_UNROLL
+    for (int l = 0; l <= NL; ++l) {
+      double Bl;
+      if (!(narrow && cplkavg_fast(c2lo, c2hi, sc[l], sc[171 + l], sc[150 + l], &Bl)))
+        Bl = cplkavg_dev(wnumlo, wnumhi, sc[l], sc[NLEV + l]);
+      st[l][lane] = Bl;
+    }
+    all_angles<EXPV, CUBE>(d, tau, (const double(*)[64]) & st[0][lane], Ed, Eu);
   }
   store_partial(d, col, chunk, lane, valid, Ed, Eu);
 }
@@ -267,18 +319,15 @@ __global__ __launch_bounds__(64 * WPB, 2) void k_rt_repwvl(Dev d) {
   const int w0 = chunk * d.chunk_len;
   const int w1 = min(w0 + d.chunk_len, d.nspec);
   for (int w = w0 + lane; w < w1; w += 64) {
-    double tau[NL], B[NL];
+    double tau[NL];
 #pragma unroll 1
     for (int l = 0; l < NL; ++l) st[l][lane] = repwvl_tau_layer(d, s, w, l);
 #pragma unroll
-    for (int l = 0; l < NL; ++l) tau[l] = st[l][lane];
+    for (int l = 0; l < NL; ++l) tau[l] = EXPV ? clamp_tau(st[l][lane]) : st[l][lane];
     const double pnum = d.pnum[w], lam5 = d.lam5[w], lkb = d.lkb[w];
 #pragma unroll 1
     for (int l = 0; l <= NL; ++l) st[l][lane] = planck_mono(pnum, lam5, lkb, s.T[l]);  // main.cpp:331, :301
-#pragma unroll
-    for (int l = 0; l < NL; ++l) B[l] = st[l][lane];
-    const double Bs = st[NL][lane];
-    all_angles<EXPV, CUBE>(d, tau, B, Bs, Ed, Eu);
+    all_angles<EXPV, CUBE>(d, tau, (const double(*)[64]) & st[0][lane], Ed, Eu);
   }
   store_partial(d, col, chunk, lane, valid, Ed, Eu);
 }
@@ -459,7 +508,7 @@ struct rcm_ensemble {
   bool have_grid = false, have_columns = false;
   long long step_index = 0;  // the reference's loop variable i (main.cpp:531)
   int user_chunks = 0;
-  int exp_variant = 1, cube = 1;
+  int exp_variant = 1, cube = 1, planck_fast = 1;
   std::vector<double> plevel, player, conv;
   std::vector<void *> allocs;
   Dev d{};
@@ -564,9 +613,14 @@ int ensure_partials(rcm_ensemble *h) {
 
 template <int EXPV, int CUBE>
 void launch_rt(rcm_ensemble *h, int blocks) {
-  if (h->mode == rcm::MODE_LBL)
-    hipLaunchKernelGGL((rcm::k_rt_lbl<EXPV, CUBE>), dim3(blocks), dim3(64 * rcm::WPB), 0, h->stream, h->d);
-  else
+  if (h->mode == rcm::MODE_LBL) {
+#ifndef RCM_EXPERIMENT
+    if (!h->planck_fast)
+      hipLaunchKernelGGL((rcm::k_rt_lbl<EXPV, CUBE, 0>), dim3(blocks), dim3(64 * rcm::WPB), 0, h->stream, h->d);
+    else
+#endif
+      hipLaunchKernelGGL((rcm::k_rt_lbl<EXPV, CUBE, 1>), dim3(blocks), dim3(64 * rcm::WPB), 0, h->stream, h->d);
+  } else
     hipLaunchKernelGGL((rcm::k_rt_repwvl<EXPV, CUBE>), dim3(blocks), dim3(64 * rcm::WPB), 0, h->stream, h->d);
 }
 
@@ -589,6 +643,12 @@ int launch_step(rcm_ensemble *h) {
     ++h->events_used;
     HIPCK(hipEventRecord(e0, h->stream));
   }
+#ifdef RCM_EXPERIMENT  // quick A/B builds: only the EXPV = 1 instantiations
+  if (!h->cube)
+    launch_rt<1, 0>(h, blocks);
+  else
+    launch_rt<1, 1>(h, blocks);
+#else
   if (h->exp_variant == 0 && !h->cube)
     launch_rt<0, 0>(h, blocks);
   else if (h->exp_variant == 0 && h->cube)
@@ -597,6 +657,7 @@ int launch_step(rcm_ensemble *h) {
     launch_rt<1, 0>(h, blocks);
   else
     launch_rt<1, 1>(h, blocks);
+#endif
   if (h->timing) HIPCK(hipEventRecord(e1, h->stream));
   hipLaunchKernelGGL(rcm::k_post, dim3(h->ncol), dim3(64), 0, h->stream, d);
   HIPCK(hipGetLastError());
@@ -625,6 +686,7 @@ int rcm_create(int ncol, int nlayer, int nangle, int device, void *stream, rcm_e
   h->ncol = ncol, h->nlayer = nlayer, h->nangle = nangle, h->device = device;
   if (const char *v = std::getenv("RCM_EXP_VARIANT")) h->exp_variant = std::atoi(v) ? 1 : 0;
   if (const char *v = std::getenv("RCM_CUBE")) h->cube = std::atoi(v) ? 1 : 0;
+  if (const char *v = std::getenv("RCM_PLANCK_FAST")) h->planck_fast = std::atoi(v) ? 1 : 0;
   auto bail = [&](int rc) {
     rcm_destroy(h);
     return rc;

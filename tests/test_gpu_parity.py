@@ -101,20 +101,34 @@ def test_lbl_wide_bands_take_the_series_branches(pkg, olib):
     _check_state(g, o)
 
 
+def test_lbl_narrow_bands_take_the_fast_planck_path(pkg, olib):
+    # 3000 nodes over 9.9..10.1 um: hh = v * 6.7e-6 < 2e-3 -> midpoint+curvature path of cplkavg_fast;
+    # the oracle runs the reference's Simpson iteration
+    inp = H.make_inputs(pkg, "lbl", 3, n_nodes=3000, atm="fpda.lbl.atm")
+    inp["wvl"] = np.linspace(9900.0, 10100.0, 3000)
+    g, o = H.gpu_ensemble(pkg, inp), H.oracle_ensemble(olib, inp)
+    g.step(1), o.step(1)
+    fg, fo = g.get_fluxes(), o.get_fluxes()
+    assert fo["E_up"][0, 20] > 0.5  # W/m^2 in this 0.2 um slice
+    for k in fo:
+        assert H.max_abs(fg[k], fo[k]) <= 1e-12, k  # 3 W/m^2 total, 4e-15 relative
+
+
 def test_chunking_and_kernel_variants_agree(pkg, olib, monkeypatch):
     inp = H.make_inputs(pkg, "lbl", 3, n_nodes=1500, atm="fpda.lbl.atm")
     o = H.oracle_ensemble(olib, inp)
     o.step(2)
     fo = o.get_fluxes()
-    for expv, cube, chunks in ((0, 0, 1), (1, 0, 0), (0, 1, 5), (1, 1, 24), (1, 1, 3)):
+    for expv, cube, chunks, plk in ((0, 0, 1, 0), (1, 0, 0, 1), (0, 1, 5, 1), (1, 1, 24, 0), (1, 1, 3, 1)):
         monkeypatch.setenv("RCM_EXP_VARIANT", str(expv))
         monkeypatch.setenv("RCM_CUBE", str(cube))
+        monkeypatch.setenv("RCM_PLANCK_FAST", str(plk))
         g = H.gpu_ensemble(pkg, inp)
         g.set_spectral_chunks(chunks)
         g.step(2)
         fg = g.get_fluxes()
         for k in fo:
-            assert H.max_abs(fg[k], fo[k]) <= FLUX_TIGHT, (expv, cube, chunks, k)
+            assert H.max_abs(fg[k], fo[k]) <= FLUX_TIGHT, (expv, cube, chunks, plk, k)
         g.close()
 
 

@@ -15,13 +15,13 @@ import our_first_climate_model_amd as pkg
 ncol = int(sys.argv[1]) if len(sys.argv) > 1 else 2048
 nodes = int(sys.argv[2]) if len(sys.argv) > 2 else 131072
 rounds = int(sys.argv[3]) if len(sys.argv) > 3 else 3
-variants = [v for v in os.environ.get("SWEEP", "0:0:0,1:0:0,0:1:0,1:1:0,1:1:4,1:1:16").split(",")]
+variants = [v for v in os.environ.get("SWEEP", "0:0:0:0,1:1:0:0,1:0:0:1,1:1:0:1,1:1:16:1").split(",")]
 
 inp = H.make_inputs(pkg, "lbl", ncol, n_nodes=nodes, atm="fpda.lbl.atm")
 ens = {}
 for v in variants:
-    e, c, k = (int(x) for x in v.split(":"))
-    os.environ["RCM_EXP_VARIANT"], os.environ["RCM_CUBE"] = str(e), str(c)
+    e, c, k, pl = (int(x) for x in v.split(":"))
+    os.environ["RCM_EXP_VARIANT"], os.environ["RCM_CUBE"], os.environ["RCM_PLANCK_FAST"] = str(e), str(c), str(pl)
     g = H.gpu_ensemble(pkg, inp)
     g.set_spectral_chunks(k)
     g.step(1)
@@ -37,6 +37,6 @@ for r in range(rounds):
 pts = ncol * (nodes - 1)
 for v in variants:
     t = np.array(times[v])
-    print(f"exp:cube:chunks={v:8s} median {np.median(t):9.3f} ms  min {t.min():9.3f} ms  "
+    print(f"exp:cube:chunks:planck={v:10s} median {np.median(t):9.3f} ms  min {t.min():9.3f} ms  "
           f"{pts / np.median(t) / 1e6:8.2f} Gpoint/s  alg {808 * pts / np.median(t) / 1e6:8.1f} GB/s "
           f"chunks={ens[v].get_spectral_chunks()}")
