@@ -1,0 +1,222 @@
+// rcm_main.cpp -- drop-in for the reference's main() (main.cpp:353-596) on top of the C ABI.
+//
+// Same sequence: read the atmosphere file, build the layer quantities, load the optical-depth
+// tables, solar set-up, banner, then the time loop i = 0..n_steps INCLUSIVE with an output_conv
+// block every output_steps iterations BEFORE that iteration's radiative transfer, all appended to
+// output.txt in the reference's formats.  What the reference compiles in (Consts, main.cpp:66-92;
+// file paths main.cpp:397,500; CO2 factor main.cpp:452) is a command-line option here, with the
+// reference's value as the default.  The loop body runs on the GPU (rcm_step); with --ncol N the
+// column is replicated into a CO2 sweep and column 0.. are integrated together.
+//
+//   rcm_main [--atm F] [--table F.rtab | --lbl-dir D] [--steps N] [--output-steps K]
+//            [--co2-factor X] [--ncol N] [--tsfc T] [--output F] [--device I] [--print-col C]
+#include <chrono>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "rcm.h"
+
+namespace {
+
+struct Options {
+  std::string atm = "./repwvl_V2.01_cpp/test.atm";                // main.cpp:397
+  std::string table = "./repwvl_V2.01_cpp/Reduced100Forcing.rtab"; // main.cpp:500 (flattened .nc)
+  std::string lbl_dir;
+  std::string output = "output.txt";                               // main.cpp:105,512
+  int steps = 1;          // Consts::n_steps, main.cpp:83
+  int output_steps = 10;  // Consts::output_steps, main.cpp:84
+  double co2_factor = 1;  // main.cpp:452
+  double tsfc = 288.2;    // main.cpp:357
+  double tau_s = 2.0;     // main.cpp:86
+  int ncol = 1, device = 0, print_col = 0;
+};
+
+[[noreturn]] void die(const std::string &what) {
+  std::fprintf(stderr, "rcm_main: %s: %s\n", what.c_str(), rcm_last_error());
+  std::exit(1);
+}
+
+#define CK(call)                 \
+  do {                           \
+    if ((call) != RCM_OK) die(#call); \
+  } while (0)
+
+Options parse(int argc, char **argv) {
+  Options o;
+  for (int i = 1; i < argc; ++i) {
+    const std::string a = argv[i];
+    auto val = [&]() -> const char * {
+      if (i + 1 >= argc) {
+        std::fprintf(stderr, "rcm_main: %s needs a value\n", a.c_str());
+        std::exit(2);
+      }
+      return argv[++i];
+    };
+    if (a == "--atm") o.atm = val();
+    else if (a == "--table") o.table = val();
+    else if (a == "--lbl-dir") o.lbl_dir = val();
+    else if (a == "--output") o.output = val();
+    else if (a == "--steps") o.steps = std::atoi(val());
+    else if (a == "--output-steps") o.output_steps = std::atoi(val());
+    else if (a == "--co2-factor") o.co2_factor = std::atof(val());
+    else if (a == "--tsfc") o.tsfc = std::atof(val());
+    else if (a == "--tau-s") o.tau_s = std::atof(val());
+    else if (a == "--ncol") o.ncol = std::atoi(val());
+    else if (a == "--device") o.device = std::atoi(val());
+    else if (a == "--print-col") o.print_col = std::atoi(val());
+    else {
+      std::fprintf(stderr, "rcm_main: unknown option %s\n", a.c_str());
+      std::exit(2);
+    }
+  }
+  if (o.ncol < 1 || o.steps < 0 || o.output_steps < 1 || o.print_col < 0 || o.print_col >= o.ncol) {
+    std::fprintf(stderr, "rcm_main: bad option value\n");
+    std::exit(2);
+  }
+  return o;
+}
+
+// lbl.{co2,h2o,o3,ch4,n2o}.asc (lbl.arts/README:5-9) -> wavelength nodes + 5 tables [n][20].
+void load_lbl(const std::string &dir, int nlayer, std::vector<double> &wvl, std::vector<std::vector<double>> &tabs) {
+  const char *names[RCM_NSPEC_LBL] = {"co2", "h2o", "o3", "ch4", "n2o"};
+  tabs.assign(RCM_NSPEC_LBL, {});
+  for (int s = 0; s < RCM_NSPEC_LBL; ++s) {
+    const std::string path = dir + "/lbl." + names[s] + ".asc";
+    int nx = 0, ny = 0;
+    double *x = nullptr, *y = nullptr;
+    const int st = rcm_ascii_file2xy2D(path.c_str(), &nx, &ny, &x, &y);
+    if (st != 0) {  // testlblarts.cpp:28-31
+      std::fprintf(stderr, "Error %d reading %s\n", st, path.c_str());
+      std::exit(1);
+    }
+    std::fprintf(stderr, " ... read %d wavelengths and %d layers from %s\n", nx, ny, path.c_str());  // testlblarts.cpp:33
+    if (ny != nlayer || nx < 2) {
+      std::fprintf(stderr, "rcm_main: %s: expected %d layer columns and >= 2 rows\n", path.c_str(), nlayer);
+      std::exit(1);
+    }
+    const bool descending = x[0] > x[nx - 1];  // ARTS writes frequency-ordered grids; cplkavg needs lambda ascending
+    std::vector<double> w(nx), t((size_t)nx * ny);
+    for (int r = 0; r < nx; ++r) {
+      const int src = descending ? nx - 1 - r : r;
+      w[r] = x[src];
+      std::memcpy(&t[(size_t)r * ny], &y[(size_t)src * ny], ny * sizeof(double));
+    }
+    rcm_free(x);
+    rcm_free(y);
+    if (s == 0) wvl = w;
+    else if (w != wvl) {
+      std::fprintf(stderr, "rcm_main: %s: wavelength grid differs from lbl.co2.asc\n", path.c_str());
+      std::exit(1);
+    }
+    tabs[s] = std::move(t);
+  }
+}
+
+}  // namespace
+
+int main(int argc, char **argv) {
+  const Options o = parse(argc, argv);
+  const int nlayer = 20, nlevel = 21, nangle = 30;  // main.cpp:78-80
+
+  // ---- profiles: main.cpp:396-485 ------------------------------------------------------------
+  std::vector<double> atm(9 * (size_t)nlevel);
+  int nlev_read = 0, ncols_found = 0;
+  CK(rcm_atm_load(o.atm.c_str(), nlevel, atm.data(), &nlev_read, &ncols_found));
+  if (nlev_read != nlevel) {
+    std::fprintf(stderr, "rcm_main: %s has %d levels, need %d\n", o.atm.c_str(), nlev_read, nlevel);
+    return 1;
+  }
+  const bool lbl = !o.lbl_dir.empty();
+  const int ngas = lbl ? RCM_NSPEC_LBL : RCM_NSPEC_REPWVL;
+  std::vector<double> plevel(nlevel), player(nlayer), Tlayer(nlayer), conv(nlayer), vmr9(9 * (size_t)nlayer),
+      rel(nlayer), h2o_ref(nlayer);
+  CK(rcm_column_init(nlevel, atm.data(), 1.0, 1.0, plevel.data(), player.data(), Tlayer.data(), conv.data(),
+                     vmr9.data(), rel.data()));
+  std::copy(vmr9.begin(), vmr9.begin() + nlayer, h2o_ref.begin());
+
+  std::vector<double> T0((size_t)o.ncol * nlayer), Ts0(o.ncol, o.tsfc), gas((size_t)o.ncol * ngas * nlayer),
+      relhum((size_t)o.ncol * nlayer);
+  for (int c = 0; c < o.ncol; ++c) {
+    // one column: the reference's factor; an ensemble: factor * linspace(0.5, 4.0)
+    const double f = o.ncol == 1 ? o.co2_factor : o.co2_factor * (0.5 + 3.5 * c / (double)(o.ncol - 1));
+    CK(rcm_column_init(nlevel, atm.data(), f, 1.0, plevel.data(), player.data(), Tlayer.data(), conv.data(),
+                       vmr9.data(), rel.data()));
+    std::copy(Tlayer.begin(), Tlayer.end(), T0.begin() + (size_t)c * nlayer);
+    std::copy(rel.begin(), rel.end(), relhum.begin() + (size_t)c * nlayer);
+    double *g = &gas[(size_t)c * ngas * nlayer];
+    if (lbl) {
+      for (int i = 0; i < ngas * nlayer; ++i) g[i] = 1.0;
+      for (int l = 0; l < nlayer; ++l) g[l] = f;  // CO2 table multiplier
+    } else {
+      std::copy(vmr9.begin(), vmr9.end(), g);
+    }
+  }
+
+  // ---- ensemble + optical-depth tables: main.cpp:494-504 -------------------------------------
+  rcm_ensemble *h = nullptr;
+  CK(rcm_create(o.ncol, nlayer, nangle, o.device, nullptr, &h));
+  CK(rcm_set_grid(h, plevel.data()));
+  if (lbl) {
+    std::vector<double> wvl;
+    std::vector<std::vector<double>> tabs;
+    load_lbl(o.lbl_dir, nlayer, wvl, tabs);
+    const double *tp[RCM_NSPEC_LBL];
+    for (int s = 0; s < RCM_NSPEC_LBL; ++s) tp[s] = tabs[s].data();
+    CK(rcm_set_lbl_tables(h, (int)wvl.size(), wvl.data(), tp, h2o_ref.data()));
+  } else {
+    long long dims[4];
+    double *blob = nullptr;
+    CK(rcm_rtab_load(o.table.c_str(), dims, &blob));
+    const size_t nt = dims[0], ns = dims[1], nw = dims[2], np = dims[3];
+    const double *p_grid = blob, *t_ref = p_grid + np, *t_pert = t_ref + np, *vmrs_ref = t_pert + nt,
+                 *wvl = vmrs_ref + ns * np, *weight = wvl + nw, *xsec = weight + nw;
+    CK(rcm_set_repwvl_tables(h, (int)nt, (int)ns, (int)nw, (int)np, p_grid, t_ref, t_pert, wvl, weight, xsec));
+    rcm_free(blob);
+  }
+
+  // ---- solar set-up + banner: main.cpp:512-519, 528 -------------------------------------------
+  double solar[7];
+  const double mu_s = std::cos(60 * M_PI / 180.0);  // main.cpp:87
+  CK(rcm_solar_setup(o.tau_s, mu_s, 20, 0.85, 0.12, (double)0.5f, 1361.0, solar));
+  CK(rcm_set_forcing(h, solar[6], 17, o.tau_s / 2.0));  // main.cpp:92, 267
+  CK(rcm_set_columns(h, T0.data(), Ts0.data(), gas.data(), relhum.data()));
+  FILE *out = std::fopen(o.output.c_str(), "a");  // main.cpp:512 (append)
+  if (!out) {
+    std::fprintf(stderr, "rcm_main: cannot open %s\n", o.output.c_str());
+    return 1;
+  }
+  CK(rcm_write_banner(out, o.tau_s, mu_s, solar));
+
+  // ---- model run: main.cpp:531-583 ------------------------------------------------------------
+  std::vector<double> Tadj(nlayer), theta(nlayer);
+  float time_h = 0.f;
+  const auto t0 = std::chrono::steady_clock::now();
+  int i = 0;
+  while (i <= o.steps) {
+    if (i % o.output_steps == 0) {  // main.cpp:543-546, before this iteration's radiative transfer
+      CK(rcm_get_profile(h, o.print_col, Tadj.data(), theta.data(), &time_h));
+      CK(rcm_write_profile(out, nlayer, player.data(), Tadj.data(), theta.data(), time_h));
+    }
+    const int next_out = (i / o.output_steps + 1) * o.output_steps;
+    const int run = std::min(next_out, o.steps + 1) - i;  // iterations until the next output or the end
+    CK(rcm_step(h, run));
+    i += run;
+  }
+  CK(rcm_sync(h));
+  const double secs = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+  std::fclose(out);
+
+  std::vector<double> Tsfc(o.ncol);
+  std::vector<float> tm(o.ncol);
+  CK(rcm_get_state(h, nullptr, Tsfc.data(), tm.data(), nullptr));
+  std::fprintf(stderr, "rcm_main: %d column(s) x %d iterations (%d spectral points) in %.3f s = %.1f column-timesteps/s\n",
+               o.ncol, o.steps + 1, rcm_nspectral(h), secs, o.ncol * (double)(o.steps + 1) / secs);
+  std::fprintf(stderr, "rcm_main: column %d: T_surface %.10f K, time %.6f h\n", o.print_col, Tsfc[o.print_col],
+               tm[o.print_col]);
+  CK(rcm_destroy(h));
+  return 0;
+}

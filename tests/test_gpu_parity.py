@@ -246,3 +246,62 @@ def test_full_spectrum_chunking_invariance_and_replica_identity(pkg, big):
         assert np.all(f0[k] == f0[k][:1]), "identical columns must give bit-identical results"
         assert H.max_abs(f0[k], f1[k]) <= FLUX_TIGHT
     assert H.max_abs(s0["Tlayer"], s1["Tlayer"]) <= 1e-9
+
+
+# ---- the C++ driver (drop-in for main()) ----------------------------------------------------------
+def _run_driver(args, cwd):
+    import subprocess
+    exe = os.path.join(H.ROOT, "our_first_climate_model_amd", "rcm_main")
+    assert os.path.exists(exe), "rcm_main not built (python -m our_first_climate_model_amd.build)"
+    r = subprocess.run([exe] + args, cwd=cwd, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr
+    return r
+
+
+def test_driver_writes_reference_output_txt(pkg, olib, golden, tmp_path):
+    # main.cpp with n_steps = 20, output_steps = 10, Reduced10: banner + 3 blocks of 20 rows
+    _run_driver(["--atm", os.path.join(golden, "test.atm"), "--table", os.path.join(golden, "Reduced10Forcing.rtab"),
+                 "--steps", "20", "--output-steps", "10"], tmp_path)
+    got = (tmp_path / "output.txt").read_text().splitlines()
+    ref = open(os.path.join(golden, "reference_output.txt")).read().splitlines()
+    assert got[0] == "" and got[1] == ref[1]
+    assert got[2] == ("Planetary albedo for an optical thickness of 2.000 and an cos(SZA) of 0.50: 0.303798 ")
+    assert got[3] == "rdir 0.230769, sdir 0.220419, and tdir 0.548812 "  # SURVEY.md section 4 [probe]
+    assert got[5] == "solar irradiance: 236.882897 "
+    assert got[6] == ref[6] and got[7:27] == ref[7:27]  # header + t = 0 rows of output.txt:7-27
+    assert len(got) == 7 + 3 * 20
+    # later blocks against the oracle stepping the same column
+    inp = H.make_inputs(pkg, "repwvl", 1, table="Reduced10", perturb=False)
+    o = H.oracle_ensemble(olib, inp)
+    for blk in (1, 2):
+        o.step(10)
+        T, th, tm = o.get_profile(0)
+        want = [f"{i},{inp['cols']['player'][i]:f},{T[i]:f},{th[i]:f},{tm:f}" for i in range(20)]
+        assert got[7 + 20 * blk: 27 + 20 * blk] == want
+    # appending, like freopen(..., "a")
+    _run_driver(["--atm", os.path.join(golden, "test.atm"), "--table", os.path.join(golden, "Reduced10Forcing.rtab"),
+                 "--steps", "0"], tmp_path)
+    assert len((tmp_path / "output.txt").read_text().splitlines()) == 67 + 7 + 20
+
+
+def test_driver_lbl_directory(pkg, olib, golden, tmp_path):
+    # five lbl.xxx.asc files in the README format (wavelength + 20 layer columns), one written
+    # frequency-ordered (descending wavelength) with comments, through the ASCII loader
+    n = 300
+    inp = H.make_inputs(pkg, "lbl", 1, n_nodes=n, atm="fpda.lbl.atm", perturb=False)
+    for s, name in enumerate(("co2", "h2o", "o3", "ch4", "n2o")):
+        m = np.concatenate([inp["wvl"][:, None], inp["tabs"][s]], axis=1)
+        if name == "o3":
+            m = m[::-1]
+        with open(tmp_path / f"lbl.{name}.asc", "w") as f:
+            f.write("% synthetic lbl table\n")
+            for row in m:
+                f.write(" ".join(f"{v:.17g}" for v in row) + "\n")
+    _run_driver(["--atm", os.path.join(golden, "fpda.lbl.atm"), "--lbl-dir", str(tmp_path), "--steps", "5",
+                 "--output-steps", "5"], tmp_path)
+    got = (tmp_path / "output.txt").read_text().splitlines()
+    o = H.oracle_ensemble(olib, inp)
+    o.step(5)
+    T, th, tm = o.get_profile(0)
+    want = [f"{i},{inp['cols']['player'][i]:f},{T[i]:f},{th[i]:f},{tm:f}" for i in range(20)]
+    assert got[27:47] == want

@@ -1,0 +1,92 @@
+"""CPU, world_size 2, gloo: the column sharding and the single end-of-run all-gather.
+The compute inside each rank is the CPU oracle here (no GPU in this container); on the MI355X node
+bench.py runs the same shard/gather code with the HIP ensemble and the nccl (= RCCL) backend."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _rank_main(rank, world, port, ncol_total, q):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import torch
+    import torch.distributed as dist
+    import helpers as H
+    import oracle_lib as ol
+    import our_first_climate_model_amd as pkg
+    from our_first_climate_model_amd.distributed import gather_state, shard_bounds
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+    try:
+        lo, hi = shard_bounds(ncol_total, rank, world)
+        atm_cols, _ = pkg.atm_load(os.path.join(ROOT, "tests", "golden", "test.atm"))
+        spec = pkg.perturbation_sweep(hi - lo, perturb_rh=True, perturb_ts=True, first=lo, total=ncol_total)
+        cols = pkg.build_columns(atm_cols, spec, "repwvl")
+        inp = dict(mode="repwvl", ncol=hi - lo, cols=cols, solar=pkg.default_solar()["solar_irr"],
+                   table=ol.read_rtab(os.path.join(ROOT, "tests", "golden", "Reduced10Forcing.rtab")))
+        e = H.oracle_ensemble(ol.load(), inp, threads=1)
+        e.step(3)
+        s = e.get_state()
+        packed = torch.from_numpy(np.concatenate([s["Tlayer"], s["T_surface"][:, None]], axis=1))
+        full = gather_state(packed, ncol_total, world, dist)
+        if rank == 0:
+            q.put(full.numpy().copy())
+        else:
+            assert full.shape == (ncol_total, 21)
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("ncol_total", [7, 8])
+def test_two_ranks_shard_and_gather_equals_one_rank(rcm, olib, ncol_total):
+    import torch.multiprocessing as mp
+    import helpers as H
+    import oracle_lib as ol
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_rank_main, args=(r, 2, port, ncol_total, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    full = q.get(timeout=240)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    # one rank, whole ensemble
+    inp = H.make_inputs(rcm, "repwvl", ncol_total, table="Reduced10")
+    e = H.oracle_ensemble(olib, inp, threads=2)
+    e.step(3)
+    s = e.get_state()
+    want = np.concatenate([s["Tlayer"], s["T_surface"][:, None]], axis=1)
+    np.testing.assert_array_equal(full, want)  # same CPU arithmetic per column: bit-identical
+
+
+def test_shard_bounds_cover_the_ensemble_once(rcm):
+    from our_first_climate_model_amd.distributed import shard_bounds
+    for n in (1, 7, 8, 10000, 100003):
+        for world in (1, 2, 3, 4, 8):
+            edges = [shard_bounds(n, r, world) for r in range(world)]
+            assert edges[0][0] == 0 and edges[-1][1] == n
+            assert all(a[1] == b[0] for a, b in zip(edges, edges[1:]))
+            assert max(h - l for l, h in edges) == (n + world - 1) // world
+
+
+def test_sweep_windows_concatenate_to_the_full_sweep(rcm):
+    full = rcm.perturbation_sweep(11, perturb_rh=True, perturb_ts=True)
+    parts = [rcm.perturbation_sweep(hi - lo, perturb_rh=True, perturb_ts=True, first=lo, total=11)
+             for lo, hi in ((0, 6), (6, 11))]
+    for k in ("co2_factor", "rh_scale", "T_surface0"):
+        np.testing.assert_array_equal(np.concatenate([getattr(p, k) for p in parts]), getattr(full, k))
+    s0 = full.shard(1, 2)
+    np.testing.assert_array_equal(s0.co2_factor, parts[1].co2_factor)
