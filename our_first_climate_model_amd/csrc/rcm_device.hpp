@@ -47,20 +47,33 @@ constexpr double kTauMax = 1.0e7;  // exp(-1e7) == 0 for every angle
 
 __device__ __forceinline__ double clamp_tau(double tau) { return fmin(fmax(tau, kTauMin), kTauMax); }
 
+#ifndef RCM_EXP_DEG
+#define RCM_EXP_DEG 10  // degree of the transmission polynomial: 10 -> 2.9e-16, 9 -> 1.9e-14 max rel err
+#endif
+#ifndef RCM_EXP_LN2LO
+#define RCM_EXP_LN2LO 0  // second FMA of the range reduction (k * low bits of ln2): |k| * 2.3e-17 relative, not needed
+#endif
+
 __device__ __forceinline__ double exp_trans(double tau, double a1, double a2) {
   constexpr double kLn2Hi = 0x1.62e42fefa39efp-1;
-  constexpr double kLn2Lo = 0x1.abc9e3b39803fp-56;
   constexpr double kMagic = 0x1.8p+52;
-  const double z = fma(tau, a1, kMagic);
+  const double z = fma(tau, a1, kMagic);  // low word of z = k = rint(-tau*s*log2e), two's complement
   const double kf = z - kMagic;
   double r = fma(kf, -kLn2Hi, tau * a2);
-  r = fma(kf, -kLn2Lo, r);
+#if RCM_EXP_LN2LO
+  r = fma(kf, -0x1.abc9e3b39803fp-56, r);
+#endif
+#if RCM_EXP_DEG == 9
+  double p = kExpPoly9[9];
+#pragma unroll
+  for (int i = 8; i >= 0; --i) p = fma(p, r, kExpPoly9[i]);
+#else
   double p = kExpPoly10[10];
 #pragma unroll
   for (int i = 9; i >= 0; --i) p = fma(p, r, kExpPoly10[i]);
-  const int k = max(__double2loint(z), -1022);
-  const int hi = __double2hiint(p) + (int)((unsigned)k << 20);
-  return __hiloint2double(hi, __double2loint(p));
+#endif
+  // v_ldexp_f64: one instruction, denormal/zero for k < -1022 (no integer clamp needed)
+  return __builtin_amdgcn_ldexp(p, __double2loint(z));
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -35,6 +35,9 @@ constexpr int WPB = 4;       // waves per block = columns per block (one per SIM
 #ifndef RCM_SCHED4
 #define RCM_SCHED4 0  // scheduling barrier after every 4th transmission exp
 #endif
+#ifndef RCM_PAIR_LB
+#define RCM_PAIR_LB 2  // waves per SIMD the lane-pair lbl kernel is register-allocated for
+#endif
 #ifndef RCM_PLK_UNROLL
 #define RCM_PLK_UNROLL 1  // independent band-Planck evaluations in flight
 #endif
@@ -292,6 +295,168 @@ __global__ __launch_bounds__(64 * WPB, RCM_LB) void k_rt_lbl(Dev d) {
 }
 
 // ---------------------------------------------------------------------------------------------
+// Thermal RT, lbl spectra, LANE-PAIR layout (the production kernel).
+//
+// Two adjacent lanes share one band: the even lane runs the downward recurrence and owns
+// E_down[1..20], the odd lane runs the upward recurrence and owns E_up[20..0].  Both execute the
+// same instruction stream: position k of a lane is layer k (down) or layer 19-k (up), so the
+// recurrence  L = B[k] + t[k]*(L - B[k]),  acc[k+1] += w*L  is the reference's down sweep
+// (main.cpp:306-309) in even lanes and its up sweep (main.cpp:311-314) in odd lanes.  Each lane
+// evaluates the transmissions and Planck values of ITS first ten positions only and takes the other
+// ten from its partner with one DPP quad-permute per 32-bit half:  x[k] = partner.x[19-k].
+// Per lane that is 21 accumulators, 20 transmissions, 10 optical depths instead of 41/20/20: the
+// kernel fits 2-3 waves per SIMD without spilling, and no transcendental is computed twice.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ double pair_swap(double v) {
+  int lo = __double2loint(v), hi = __double2hiint(v);
+  lo = __builtin_amdgcn_update_dpp(lo, lo, 0xB1, 0xF, 0xF, true);  // quad_perm [1,0,3,2]
+  hi = __builtin_amdgcn_update_dpp(hi, hi, 0xB1, 0xF, 0xF, true);
+  return __hiloint2double(hi, lo);
+}
+
+constexpr int NH = NL / 2;  // positions a lane evaluates itself
+
+// One sweep at odd angle number m, then -- while m is divisible by 3 -- the sweep at m/3 with the
+// cubed transmissions.  Written as nested straight-line code (DEPTH levels, 3^4 = 81 covers
+// nangle <= 64) instead of a loop: a loop makes the compiler carry t[] through 20 register copies
+// per sweep.
+template <int DEPTH>
+__device__ __forceinline__ void pair_chain(const Dev &d, const double (&t)[NL], const double (&B)[NL],
+                                           double Linit, int m, double (&acc)[NLEV]) {
+  const double cw = d.ang[d.nangle + ((m - 1) >> 1)];
+  double L = Linit;
+  acc[0] = fma(cw, L, acc[0]);  // main.cpp:302 (odd lanes; even lanes add 0)
+#pragma unroll
+  for (int k = 0; k < NL; ++k) {  // main.cpp:306-309 / 311-314
+    L = fma(t[k], L - B[k], B[k]);
+    acc[k + 1] = fma(cw, L, acc[k + 1]);
+  }
+  if constexpr (DEPTH > 0) {
+    if (m % 3 == 0) {
+      double t3[NL];
+#pragma unroll
+      for (int k = 0; k < NL; ++k) t3[k] = t[k] * t[k] * t[k];
+      pair_chain<DEPTH - 1>(d, t3, B, Linit, m / 3, acc);
+    }
+  }
+}
+
+// LDS image of one column, once per lane parity p (0 = down order, 1 = up order)
+struct PairLds {
+  double T[2][NH + 1];    // T[p][k] = Tlayer[layer(p,k)], k = NH: T_surface
+  double tp[2][NH + 1];   // sigdpi * T^4            (cplkavg.cpp:237)
+  double pc[2][NH + 1];   // sigdpi * T^4 * conc     (cplkavg.cpp:181)
+  double rT[2][NH + 1];   // 1/T
+  double gas[2][RCM_NSPEC_LBL][NH];
+};
+
+template <int CUBE>
+__global__ __launch_bounds__(64 * WPB, RCM_PAIR_LB) void k_rt_lbl_pair(Dev d) {
+  __shared__ PairLds s_col[WPB];
+  __shared__ double s_stage[WPB][NH + 1][64];
+  const int lane = threadIdx.x & 63;
+  const int wib = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int ncg = (d.ncol + WPB - 1) / WPB;
+  const int chunk = blockIdx.x / ncg;
+  const int colraw = (blockIdx.x - chunk * ncg) * WPB + wib;
+  const bool valid = colraw < d.ncol;
+  const int col = valid ? colraw : d.ncol - 1;
+  const int p = lane & 1;  // 0: downward lane, 1: upward lane
+  PairLds &s = s_col[wib];
+  double(*st)[64] = s_stage[wib];
+
+  // ---- column image: lanes 0..21 fill (parity, position) = (lane / 11, lane % 11)
+  if (lane < 2 * (NH + 1)) {
+    const int q = lane / (NH + 1), k = lane - q * (NH + 1);
+    const int layer = q ? NL - 1 - k : k;
+    const double t = (k == NH) ? d.Tsfc[col] : d.T[(size_t)col * NL + layer];
+    const double tp = d.sigdpi * pow(t, 4.0);
+    s.T[q][k] = t;
+    s.tp[q][k] = tp;
+    s.pc[q][k] = tp * kConc;
+    s.rT[q][k] = 1.0 / t;
+  }
+  for (int i = lane; i < 2 * RCM_NSPEC_LBL * NH; i += 64) {
+    const int q = i / (RCM_NSPEC_LBL * NH), r = i - q * (RCM_NSPEC_LBL * NH);
+    const int sp = r / NH, k = r - sp * NH;
+    const int layer = q ? NL - 1 - k : k;
+    s.gas[q][sp][k] = d.gas[((size_t)col * RCM_NSPEC_LBL + sp) * NL + layer];
+  }
+  __syncthreads();
+
+  double acc[NLEV];  // even lane: E_down[j]; odd lane: E_up[20-j]
+#pragma unroll
+  for (int j = 0; j < NLEV; ++j) acc[j] = 0.0;  // main.cpp:326-327
+
+  const long b0 = (long)chunk * d.chunk_len;
+  const long b1 = min(b0 + (long)d.chunk_len, (long)d.nspec);
+  const int na = d.nangle;
+  // the lane's first table row and the row step: layers 0,1,.. (down) or 19,18,.. (up)
+  const double *row0 = d.lbl_tab + (size_t)(p ? NL - 1 : 0) * d.lbl_ld;
+  const long rstep = p ? -d.lbl_ld : d.lbl_ld;
+  const int cloud_k = p ? NL - 1 - d.cloud_layer : d.cloud_layer;  // position of the cloud layer, if < NH
+
+  for (long b = b0 + (lane >> 1); b < b1; b += 32) {  // main.cpp:329: 32 bands per wave pass
+    // ---- optical depths of the lane's ten layers (lbl composition + cloud, main.cpp:266-274)
+    double tau[NH];
+    {
+      const double *rp = row0 + b;
+#pragma unroll 2
+      for (int k = 0; k < NH; ++k, rp += rstep) {  // rolled: keeps the loads in flight (and their VGPRs) bounded
+        double a = 0.0;
+#pragma unroll
+        for (int sp = 0; sp < RCM_NSPEC_LBL; ++sp) a = fma(s.gas[p][sp][k], rp[(size_t)sp * NL * d.lbl_ld], a);
+        if (k == cloud_k) a += d.cloud_tau;
+        st[k][lane] = clamp_tau(a);
+      }
+#pragma unroll
+      for (int k = 0; k < NH; ++k) tau[k] = st[k][lane];
+    }
+    // ---- band Planck source of the lane's ten layers and of the surface (cplkavg.cpp:124-243)
+    const double wnumhi = 1.0E7 / d.lbl_wvl[b];      // cplkavg.cpp:141
+    const double wnumlo = 1.0E7 / d.lbl_wvl[b + 1];  // cplkavg.cpp:142
+    const double c2lo = 1.438786 * wnumlo, c2hi = 1.438786 * wnumhi;  // cplkavg.cpp:152-153
+    const bool narrow = (wnumhi - wnumlo) / wnumhi < 1.e-2;           // cplkavg.cpp:155
+#pragma unroll 1
+    for (int k = 0; k <= NH; ++k) {
+      double Bk;
+      if (!(narrow && cplkavg_fast(c2lo, c2hi, s.T[p][k], s.rT[p][k], s.pc[p][k], &Bk)))
+        Bk = cplkavg_dev(wnumlo, wnumhi, s.T[p][k], s.tp[p][k]);
+      st[k][lane] = Bk;
+    }
+    double B[NL];
+#pragma unroll
+    for (int k = 0; k < NH; ++k) B[k] = st[k][lane];
+#pragma unroll
+    for (int k = NH; k < NL; ++k) B[k] = pair_swap(B[NL - 1 - k]);
+    const double Linit = p ? st[NH][lane] : 0.0;  // main.cpp:300-301
+
+    // ---- angles (main.cpp:297), roots n = 2i+1 with 3n > 2*nangle-1 by exp, the rest by cubing
+    const int N = 2 * na - 1;
+    for (int n = N; CUBE ? 3 * n > N : n >= 1; n -= 2) {
+      const double a2 = -d.ang[(n - 1) >> 1], a1 = a2 * 0x1.71547652b82fep+0;
+      double t[NL];
+#pragma unroll
+      for (int k = 0; k < NH; ++k) t[k] = exp_trans(tau[k], a1, a2);  // main.cpp:209
+#pragma unroll
+      for (int k = NH; k < NL; ++k) t[k] = pair_swap(t[NL - 1 - k]);
+      pair_chain<CUBE ? 4 : 0>(d, t, B, Linit, n, acc);
+    }
+  }
+
+  // ---- reduce over the 32 lanes of each parity; lanes 0 / 1 hold the wave's E_down / E_up
+  double *out = d.partial + ((size_t)col * d.nchunk + chunk) * PSTRIDE;
+#pragma unroll
+  for (int j = 0; j < NLEV; ++j) {
+    double v = acc[j];
+#pragma unroll
+    for (int off = 32; off >= 2; off >>= 1) v += __shfl_xor(v, off, 64);
+    if (valid && lane == 0) out[j] = v;                    // E_down[j]
+    if (valid && lane == 1) out[NLEV + (NLEV - 1 - j)] = v;  // E_up[20-j]
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
 // Thermal RT, repwvl reduced-wavelength set: read_tau interpolation (repwvl_thermal.cpp:197-248)
 // fused with radiative_transfer (main.cpp:320-344, monochromatic Planck main.cpp:186-204).
 // tau never touches HBM.
@@ -508,7 +673,7 @@ struct rcm_ensemble {
   bool have_grid = false, have_columns = false;
   long long step_index = 0;  // the reference's loop variable i (main.cpp:531)
   int user_chunks = 0;
-  int exp_variant = 1, cube = 1, planck_fast = 1;
+  int exp_variant = 1, cube = 1, planck_fast = 1, pair = 1;
   std::vector<double> plevel, player, conv;
   std::vector<void *> allocs;
   Dev d{};
@@ -581,15 +746,16 @@ int derive_repwvl_layers(rcm_ensemble *h) {
   return RCM_OK;
 }
 
-// Spectral chunking: enough waves to fill 256 CUs x 8 resident waves several times over, but
-// never more chunks than 64-point rows.  Pure function of (ncol, nspec, user override).
+// Spectral chunking: ~16 rounds of the 2048 waves the chip holds at 2 waves/SIMD (a short tail and
+// room for the dispatcher), but never more chunks than 64-point rows.  Pure function of
+// (ncol, nspec, user override).
 void choose_chunks(int ncol, int nspec, int user_chunks, int *nchunk_out, int *chunk_len_out) {
   const int rows = (nspec + 63) / 64;
   int nchunk;
   if (user_chunks > 0) {
     nchunk = user_chunks;
   } else {
-    const long target_waves = 256L * 8 * 4;
+    const long target_waves = 256L * 8 * 16;
     nchunk = (int)((target_waves + ncol - 1) / ncol);
   }
   if (nchunk > rows) nchunk = rows;
@@ -613,7 +779,9 @@ int ensure_partials(rcm_ensemble *h) {
 
 template <int EXPV, int CUBE>
 void launch_rt(rcm_ensemble *h, int blocks) {
-  if (h->mode == rcm::MODE_LBL) {
+  if (h->mode == rcm::MODE_LBL && EXPV == 1 && h->planck_fast && h->pair) {
+    hipLaunchKernelGGL((rcm::k_rt_lbl_pair<CUBE>), dim3(blocks), dim3(64 * rcm::WPB), 0, h->stream, h->d);
+  } else if (h->mode == rcm::MODE_LBL) {
 #ifndef RCM_EXPERIMENT
     if (!h->planck_fast)
       hipLaunchKernelGGL((rcm::k_rt_lbl<EXPV, CUBE, 0>), dim3(blocks), dim3(64 * rcm::WPB), 0, h->stream, h->d);
@@ -687,6 +855,7 @@ int rcm_create(int ncol, int nlayer, int nangle, int device, void *stream, rcm_e
   if (const char *v = std::getenv("RCM_EXP_VARIANT")) h->exp_variant = std::atoi(v) ? 1 : 0;
   if (const char *v = std::getenv("RCM_CUBE")) h->cube = std::atoi(v) ? 1 : 0;
   if (const char *v = std::getenv("RCM_PLANCK_FAST")) h->planck_fast = std::atoi(v) ? 1 : 0;
+  if (const char *v = std::getenv("RCM_PAIR")) h->pair = std::atoi(v) ? 1 : 0;
   auto bail = [&](int rc) {
     rcm_destroy(h);
     return rc;

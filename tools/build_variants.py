@@ -28,7 +28,7 @@ def build(spec):
     info = []
     lines = r.stderr.splitlines()
     for i, ln in enumerate(lines):
-        if "Function Name: _ZN3rcm8k_rt_lbl" in ln:
+        if "Function Name: _ZN3rcm13k_rt_lbl_pairILi1" in ln:
             blk = " ".join(x.split("remark:")[1].split("[-R")[0].strip() for x in lines[i:i + 12]
                            if any(k in x for k in ("Function Name", " VGPRs:", "AGPRs", "ScratchSize", "VGPRs Spill")))
             info.append(blk)
