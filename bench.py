@@ -25,6 +25,19 @@ HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 BYTES_PER_BAND = 5 * 20 * 8 + 8  # 5 species x 20 layers x f64 + the wavelength
 
 
+def host_cores():
+    """CPU threads this job may really use: the affinity mask capped by the cgroup CPU quota (the GPU
+    box exposes 256 hardware threads but grants one GPU's share of them)."""
+    n = len(os.sched_getaffinity(0))
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(float(quota) / float(period) + 0.5)))
+    except (OSError, ValueError):
+        pass
+    return n
+
+
 def cpu_baseline(pkg, inp_full, n_nodes, log):
     """The CPU oracle (a port of the reference; main.cpp itself needs netcdf and cannot be built here)
     timed on this host's cores on a bounded sample of the same workload."""
@@ -32,7 +45,7 @@ def cpu_baseline(pkg, inp_full, n_nodes, log):
     import helpers as H
     import oracle_lib as ol
     olib = ol.load()
-    cores = len(os.sched_getaffinity(0))
+    cores = host_cores()
     ncol = 2 * cores
     inp = dict(inp_full)
     inp["ncol"] = ncol

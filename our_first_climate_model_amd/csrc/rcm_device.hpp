@@ -48,7 +48,7 @@ constexpr double kTauMax = 1.0e7;  // exp(-1e7) == 0 for every angle
 __device__ __forceinline__ double clamp_tau(double tau) { return fmin(fmax(tau, kTauMin), kTauMax); }
 
 #ifndef RCM_EXP_DEG
-#define RCM_EXP_DEG 10  // degree of the transmission polynomial: 10 -> 2.9e-16, 9 -> 1.9e-14 max rel err
+#define RCM_EXP_DEG 9  // degree of the transmission polynomial: 9 -> 7.4e-14, 10 -> 1.2e-15 max rel err (c0 = c1 = 1 exactly)
 #endif
 #ifndef RCM_EXP_LN2LO
 #define RCM_EXP_LN2LO 0  // second FMA of the range reduction (k * low bits of ln2): |k| * 2.3e-17 relative, not needed

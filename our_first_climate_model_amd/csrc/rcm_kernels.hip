@@ -297,15 +297,18 @@ __global__ __launch_bounds__(64 * WPB, RCM_LB) void k_rt_lbl(Dev d) {
 // ---------------------------------------------------------------------------------------------
 // Thermal RT, lbl spectra, LANE-PAIR layout (the production kernel).
 //
-// Two adjacent lanes share one band: the even lane runs the downward recurrence and owns
-// E_down[1..20], the odd lane runs the upward recurrence and owns E_up[20..0].  Both execute the
-// same instruction stream: position k of a lane is layer k (down) or layer 19-k (up), so the
-// recurrence  L = B[k] + t[k]*(L - B[k]),  acc[k+1] += w*L  is the reference's down sweep
-// (main.cpp:306-309) in even lanes and its up sweep (main.cpp:311-314) in odd lanes.  Each lane
-// evaluates the transmissions and Planck values of ITS first ten positions only and takes the other
-// ten from its partner with one DPP quad-permute per 32-bit half:  x[k] = partner.x[19-k].
-// Per lane that is 21 accumulators, 20 transmissions, 10 optical depths instead of 41/20/20: the
-// kernel fits 2-3 waves per SIMD without spilling, and no transcendental is computed twice.
+// Two adjacent lanes share one band and split the COLUMN: the even lane owns layers 0..9, the odd
+// lane layers 19..10 (position k of a lane = layer k, resp. 19-k).  Each lane forms the optical
+// depths, Planck values and transmissions of its own ten layers only -- nothing transcendental is
+// computed twice and nothing but one radiance crosses lanes:
+//   phase 1 (k = 0..9):  even lane runs the reference's DOWN recurrence through layers 0..9
+//                        (main.cpp:306-309, levels 1..10); odd lane runs the UP recurrence through
+//                        layers 19..10 (main.cpp:311-314, levels 19..10), starting from the surface.
+//   hand-over:           the two radiances at level 10 swap lanes (one DPP quad-permute per half).
+//   phase 2 (k = 9..0):  even lane continues the UP recurrence through layers 9..0 (levels 9..0);
+//                        odd lane continues the DOWN recurrence through layers 10..19 (levels 11..20).
+// Both lanes execute one instruction stream:  L = B[k] + t[k]*(L - B[k]);  acc += w*L.
+// Per lane: 21 accumulators, 10 transmissions, 10 Planck values, 10 optical depths.
 // ---------------------------------------------------------------------------------------------
 __device__ __forceinline__ double pair_swap(double v) {
   int lo = __double2loint(v), hi = __double2hiint(v);
@@ -314,34 +317,39 @@ __device__ __forceinline__ double pair_swap(double v) {
   return __hiloint2double(hi, lo);
 }
 
-constexpr int NH = NL / 2;  // positions a lane evaluates itself
+constexpr int NH = NL / 2;  // layers per lane
 
-// One sweep at odd angle number m, then -- while m is divisible by 3 -- the sweep at m/3 with the
-// cubed transmissions.  Written as nested straight-line code (DEPTH levels, 3^4 = 81 covers
-// nangle <= 64) instead of a loop: a loop makes the compiler carry t[] through 20 register copies
-// per sweep.
+// One angle (odd angle number m) on the lane pair, then -- while m is divisible by 3 -- the angle m/3
+// with the cubed transmissions (t_{m/3} = t_m^3).  Nested straight-line code (DEPTH levels; 3^4 = 81
+// covers nangle <= 64) instead of a loop: a loop makes the compiler carry t[] through register copies.
 template <int DEPTH>
-__device__ __forceinline__ void pair_chain(const Dev &d, const double (&t)[NL], const double (&B)[NL],
-                                           double Linit, int m, double (&acc)[NLEV]) {
+__device__ __forceinline__ void pair_chain(const Dev &d, const double (&t)[NH], const double (&B)[NH],
+                                           double Linit, int m, double (&acc1)[NH + 1], double (&acc2)[NH]) {
   const double cw = d.ang[d.nangle + ((m - 1) >> 1)];
   double L = Linit;
-  acc[0] = fma(cw, L, acc[0]);  // main.cpp:302 (odd lanes; even lanes add 0)
+  acc1[0] = fma(cw, L, acc1[0]);  // main.cpp:302 in odd lanes (E_up at the surface); even lanes add 0
 #pragma unroll
-  for (int k = 0; k < NL; ++k) {  // main.cpp:306-309 / 311-314
+  for (int k = 0; k < NH; ++k) {
     L = fma(t[k], L - B[k], B[k]);
-    acc[k + 1] = fma(cw, L, acc[k + 1]);
+    acc1[k + 1] = fma(cw, L, acc1[k + 1]);
+  }
+  L = pair_swap(L);  // level 10: the down radiance moves to the odd lane, the up radiance to the even lane
+#pragma unroll
+  for (int k = NH - 1; k >= 0; --k) {
+    L = fma(t[k], L - B[k], B[k]);
+    acc2[k] = fma(cw, L, acc2[k]);
   }
   if constexpr (DEPTH > 0) {
     if (m % 3 == 0) {
-      double t3[NL];
+      double t3[NH];
 #pragma unroll
-      for (int k = 0; k < NL; ++k) t3[k] = t[k] * t[k] * t[k];
-      pair_chain<DEPTH - 1>(d, t3, B, Linit, m / 3, acc);
+      for (int k = 0; k < NH; ++k) t3[k] = t[k] * t[k] * t[k];
+      pair_chain<DEPTH - 1>(d, t3, B, Linit, m / 3, acc1, acc2);
     }
   }
 }
 
-// LDS image of one column, once per lane parity p (0 = down order, 1 = up order)
+// LDS image of one column, once per lane parity p (0: layers 0..9, 1: layers 19..10)
 struct PairLds {
   double T[2][NH + 1];    // T[p][k] = Tlayer[layer(p,k)], k = NH: T_surface
   double tp[2][NH + 1];   // sigdpi * T^4            (cplkavg.cpp:237)
@@ -361,7 +369,7 @@ __global__ __launch_bounds__(64 * WPB, RCM_PAIR_LB) void k_rt_lbl_pair(Dev d) {
   const int colraw = (blockIdx.x - chunk * ncg) * WPB + wib;
   const bool valid = colraw < d.ncol;
   const int col = valid ? colraw : d.ncol - 1;
-  const int p = lane & 1;  // 0: downward lane, 1: upward lane
+  const int p = lane & 1;
   PairLds &s = s_col[wib];
   double(*st)[64] = s_stage[wib];
 
@@ -384,14 +392,18 @@ __global__ __launch_bounds__(64 * WPB, RCM_PAIR_LB) void k_rt_lbl_pair(Dev d) {
   }
   __syncthreads();
 
-  double acc[NLEV];  // even lane: E_down[j]; odd lane: E_up[20-j]
+  // even lane: acc1[j] = E_down[j] (j = 0..10), acc2[k] = E_up[k] (k = 0..9)
+  // odd lane:  acc1[j] = E_up[20-j] (j = 0..10), acc2[k] = E_down[20-k] (k = 0..9)
+  double acc1[NH + 1], acc2[NH];
 #pragma unroll
-  for (int j = 0; j < NLEV; ++j) acc[j] = 0.0;  // main.cpp:326-327
+  for (int j = 0; j <= NH; ++j) acc1[j] = 0.0;  // main.cpp:326-327
+#pragma unroll
+  for (int j = 0; j < NH; ++j) acc2[j] = 0.0;
 
   const long b0 = (long)chunk * d.chunk_len;
   const long b1 = min(b0 + (long)d.chunk_len, (long)d.nspec);
   const int na = d.nangle;
-  // the lane's first table row and the row step: layers 0,1,.. (down) or 19,18,.. (up)
+  // the lane's first table row and the row step: layers 0,1,.. (even) or 19,18,.. (odd)
   const double *row0 = d.lbl_tab + (size_t)(p ? NL - 1 : 0) * d.lbl_ld;
   const long rstep = p ? -d.lbl_ld : d.lbl_ld;
   const int cloud_k = p ? NL - 1 - d.cloud_layer : d.cloud_layer;  // position of the cloud layer, if < NH
@@ -402,7 +414,7 @@ __global__ __launch_bounds__(64 * WPB, RCM_PAIR_LB) void k_rt_lbl_pair(Dev d) {
     {
       const double *rp = row0 + b;
 #pragma unroll 2
-      for (int k = 0; k < NH; ++k, rp += rstep) {  // rolled: keeps the loads in flight (and their VGPRs) bounded
+      for (int k = 0; k < NH; ++k, rp += rstep) {  // rolled: bounds the loads (and VGPRs) in flight
         double a = 0.0;
 #pragma unroll
         for (int sp = 0; sp < RCM_NSPEC_LBL; ++sp) a = fma(s.gas[p][sp][k], rp[(size_t)sp * NL * d.lbl_ld], a);
@@ -424,35 +436,40 @@ __global__ __launch_bounds__(64 * WPB, RCM_PAIR_LB) void k_rt_lbl_pair(Dev d) {
         Bk = cplkavg_dev(wnumlo, wnumhi, s.T[p][k], s.tp[p][k]);
       st[k][lane] = Bk;
     }
-    double B[NL];
+    double B[NH];
 #pragma unroll
     for (int k = 0; k < NH; ++k) B[k] = st[k][lane];
-#pragma unroll
-    for (int k = NH; k < NL; ++k) B[k] = pair_swap(B[NL - 1 - k]);
     const double Linit = p ? st[NH][lane] : 0.0;  // main.cpp:300-301
 
-    // ---- angles (main.cpp:297), roots n = 2i+1 with 3n > 2*nangle-1 by exp, the rest by cubing
+    // ---- angles (main.cpp:297): odd n = 2i+1; with CUBE only 3n > 2*nangle-1 needs exps
     const int N = 2 * na - 1;
     for (int n = N; CUBE ? 3 * n > N : n >= 1; n -= 2) {
       const double a2 = -d.ang[(n - 1) >> 1], a1 = a2 * 0x1.71547652b82fep+0;
-      double t[NL];
+      double t[NH];
 #pragma unroll
       for (int k = 0; k < NH; ++k) t[k] = exp_trans(tau[k], a1, a2);  // main.cpp:209
-#pragma unroll
-      for (int k = NH; k < NL; ++k) t[k] = pair_swap(t[NL - 1 - k]);
-      pair_chain<CUBE ? 4 : 0>(d, t, B, Linit, n, acc);
+      pair_chain<CUBE ? 4 : 0>(d, t, B, Linit, n, acc1, acc2);
     }
   }
 
-  // ---- reduce over the 32 lanes of each parity; lanes 0 / 1 hold the wave's E_down / E_up
+  // ---- reduce over the 32 lanes of each parity; lanes 0 / 1 then hold the wave's sums
   double *out = d.partial + ((size_t)col * d.nchunk + chunk) * PSTRIDE;
+  double *oE[2] = {out, out + NLEV};  // E_down, E_up
 #pragma unroll
-  for (int j = 0; j < NLEV; ++j) {
-    double v = acc[j];
+  for (int j = 0; j <= NH; ++j) {
+    double v = acc1[j];
 #pragma unroll
     for (int off = 32; off >= 2; off >>= 1) v += __shfl_xor(v, off, 64);
-    if (valid && lane == 0) out[j] = v;                    // E_down[j]
-    if (valid && lane == 1) out[NLEV + (NLEV - 1 - j)] = v;  // E_up[20-j]
+    if (valid && lane == 0) oE[0][j] = v;         // E_down[j], j = 0..10
+    if (valid && lane == 1) oE[1][NL - j] = v;    // E_up[20-j]
+  }
+#pragma unroll
+  for (int k = 0; k < NH; ++k) {
+    double v = acc2[k];
+#pragma unroll
+    for (int off = 32; off >= 2; off >>= 1) v += __shfl_xor(v, off, 64);
+    if (valid && lane == 0) oE[1][k] = v;         // E_up[k], k = 0..9
+    if (valid && lane == 1) oE[0][NL - k] = v;    // E_down[20-k]
   }
 }
 
