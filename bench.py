@@ -149,6 +149,15 @@ def main():
         rt_avg_s = rt_ms / 1e3 / max(rt_n, 1)
         alg_bytes = BYTES_PER_BAND * nband * ncol_local  # per RT launch on this rank
         achieved = alg_bytes / rt_avg_s / 1e9
+        # HBM bytes per launch from the PMC passes committed under profiles/ (FETCH_SIZE x 2 + WRITE_SIZE,
+        # MI355X_MICROARCH.md HBM section); only valid for the workload they were collected on
+        traffic, traffic_src = None, None
+        try:
+            prof = json.load(open(os.path.join(ROOT, "profiles", "r01_final_pmc.json")))["hbm_traffic"]
+            if prof["algorithmic_bytes_per_launch"] == alg_bytes:
+                traffic, traffic_src = prof["traffic_bytes_per_launch"], "profiles/r01_final_pmc.json"
+        except (OSError, KeyError, ValueError):
+            pass
         out = {
             "metric": "column_timesteps_per_sec", "value": ncol_total * args.steps / elapsed,
             "unit": "column-timesteps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -160,13 +169,13 @@ def main():
                        "bands": nband, "layers": 20, "angles": 30, "atmosphere": "fpda.lbl.atm",
                        "perturbations": "CO2 x linspace(0.5,4), RH x (1+0.1u), T_surface 288.2+2u",
                        "parallelism": f"columns sharded over {world} GPU(s), one all-gather at the end"},
-            "roofline": {"bound": "hbm", "kernel": "k_rt_lbl", "achieved": achieved, "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+            "roofline": {"bound": "hbm", "kernel": "k_rt_lbl_pair", "achieved": achieved, "peak": HBM_PEAK_GBS,
+                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                          "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": rt_avg_s * 1e3,
                          "launches": rt_n,
-                         "note": "808 B per (column, band) as if every column streamed the 5 species "
-                                 "tables itself; the tables are shared, so HBM traffic is far lower and "
-                                 "the kernel is bound by fp64 VALU (exp), see DESIGN.md"},
+                         "note": "numerator = 808 B per (column, band), as if every column streamed the 5 species "
+                                 "tables itself (SURVEY 8d); the tables are shared, real HBM traffic is ~1% of "
+                                 "that and the kernel is fp64-VALU-issue bound (86% VALU busy, profiles/README.md)"},
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"], oe = cpu_baseline(pkg, inp, args.nodes, log)
