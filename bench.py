@@ -71,6 +71,8 @@ def main():
     ap.add_argument("--scaling", choices=("strong", "weak"), default="strong")
     ap.add_argument("--chunks", type=int, default=0, help="spectral chunks per column (0 = auto)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--backend", default="nccl", choices=("nccl", "gloo"),
+                    help="torch.distributed backend; gloo only to rehearse the N>1 path on a one-GPU box")
     args = ap.parse_args()
 
     import numpy as np
@@ -90,10 +92,15 @@ def main():
             print(f"[bench] {msg}", file=sys.stderr, flush=True)
 
     assert torch.cuda.is_available(), "bench.py needs the MI355X (no CPU fallback)"
-    torch.cuda.set_device(local_rank)
+    dev_index = local_rank % torch.cuda.device_count()  # == local_rank on the 8-GPU node
+    torch.cuda.set_device(dev_index)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", dev_index))
+        else:
+            dist.init_process_group("gloo")
+    coll_dev = "cuda" if args.backend == "nccl" else "cpu"
 
     import our_first_climate_model_amd as pkg
     from our_first_climate_model_amd.distributed import gather_state, shard_bounds
@@ -110,7 +117,7 @@ def main():
     wvl, tabs = pkg.synth_lbl_tables(args.nodes, plevel=cols["plevel"])
     inp = dict(mode="lbl", ncol=ncol_local, cols=cols, solar=pkg.default_solar()["solar_irr"], wvl=wvl, tabs=tabs)
     stream = torch.cuda.current_stream().cuda_stream
-    ens = H.configure(pkg.Ensemble(ncol_local, device=local_rank, stream=stream), inp)
+    ens = H.configure(pkg.Ensemble(ncol_local, device=dev_index, stream=stream), inp)
     if args.chunks:
         ens.set_spectral_chunks(args.chunks)
     packed = torch.empty((ncol_local, 21), dtype=torch.float64, device="cuda")
@@ -123,22 +130,27 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    def gather():
+        ens.pack_state(packed.data_ptr())  # device buffer, on the handle's (= torch's current) stream
+        if coll_dev == "cuda":
+            return gather_state(packed, ncol_total, world, dist)
+        torch.cuda.synchronize()
+        return gather_state(packed.cpu(), ncol_total, world, dist)
+
     ens.step(args.warmup)
     if world > 1:  # warm the collective too
-        ens.pack_state(packed.data_ptr())
-        gather_state(packed, ncol_total, world, dist)
+        gather()
     barrier()
     ens.set_rt_timing(True)
     t0 = time.perf_counter()
     ens.step(args.steps)
-    ens.pack_state(packed.data_ptr())
-    final = gather_state(packed, ncol_total, world, dist)
+    final = gather()
     barrier()
     elapsed = time.perf_counter() - t0
     rt_ms, rt_n = ens.get_rt_timing()
     ens.set_rt_timing(False)
 
-    tmax = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+    tmax = torch.tensor([elapsed], dtype=torch.float64, device=coll_dev)
     if world > 1:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     elapsed = float(tmax.item())
