@@ -49,7 +49,7 @@ struct Dev {
   int ncol, nangle, mode, ngas;
   int nspec;      // spectral points: n_wvl (repwvl) or bands = n_nodes-1 (lbl)
   int nchunk;     // spectral chunks per column
-  int chunk_len;  // points per chunk (multiple of 64)
+  int chunk_len;  // points per chunk (multiple of 32)
   int cloud_layer;
   double cloud_tau, solar_irr, dp, sigdpi;
   const double *player, *conv, *ang;  // ang = [inv_mu[nangle], cw[nangle]]
@@ -349,6 +349,30 @@ __device__ __forceinline__ void pair_chain(const Dev &d, const double (&t)[NH], 
   }
 }
 
+// Reduce the accumulators over the 32 lanes of each parity (offsets 32..2) and store the record.
+// even lane: acc1[j] = E_down[j] (j = 0..10), acc2[k] = E_up[k] (k = 0..9)
+// odd lane:  acc1[j] = E_up[20-j],           acc2[k] = E_down[20-k]
+__device__ __forceinline__ void store_pair_partial(const Dev &d, int col, int chunk, int lane, bool valid,
+                                                   double (&acc1)[NH + 1], double (&acc2)[NH]) {
+  double *oEd = d.partial + ((size_t)col * d.nchunk + chunk) * PSTRIDE, *oEu = oEd + NLEV;
+#pragma unroll
+  for (int j = 0; j <= NH; ++j) {
+    double v = acc1[j];
+#pragma unroll
+    for (int off = 32; off >= 2; off >>= 1) v += __shfl_xor(v, off, 64);
+    if (valid && lane == 0) oEd[j] = v;
+    if (valid && lane == 1) oEu[NL - j] = v;
+  }
+#pragma unroll
+  for (int k = 0; k < NH; ++k) {
+    double v = acc2[k];
+#pragma unroll
+    for (int off = 32; off >= 2; off >>= 1) v += __shfl_xor(v, off, 64);
+    if (valid && lane == 0) oEu[k] = v;
+    if (valid && lane == 1) oEd[NL - k] = v;
+  }
+}
+
 // LDS image of one column, once per lane parity p (0: layers 0..9, 1: layers 19..10)
 struct PairLds {
   double T[2][NH + 1];    // T[p][k] = Tlayer[layer(p,k)], k = NH: T_surface
@@ -452,29 +476,127 @@ __global__ __launch_bounds__(64 * WPB, RCM_PAIR_LB) void k_rt_lbl_pair(Dev d) {
     }
   }
 
-  // ---- reduce over the 32 lanes of each parity; lanes 0 / 1 then hold the wave's sums
-  double *out = d.partial + ((size_t)col * d.nchunk + chunk) * PSTRIDE;
-  double *oE[2] = {out, out + NLEV};  // E_down, E_up
-#pragma unroll
-  for (int j = 0; j <= NH; ++j) {
-    double v = acc1[j];
-#pragma unroll
-    for (int off = 32; off >= 2; off >>= 1) v += __shfl_xor(v, off, 64);
-    if (valid && lane == 0) oE[0][j] = v;         // E_down[j], j = 0..10
-    if (valid && lane == 1) oE[1][NL - j] = v;    // E_up[20-j]
-  }
-#pragma unroll
-  for (int k = 0; k < NH; ++k) {
-    double v = acc2[k];
-#pragma unroll
-    for (int off = 32; off >= 2; off >>= 1) v += __shfl_xor(v, off, 64);
-    if (valid && lane == 0) oE[1][k] = v;         // E_up[k], k = 0..9
-    if (valid && lane == 1) oE[0][NL - k] = v;    // E_down[20-k]
-  }
+  store_pair_partial(d, col, chunk, lane, valid, acc1, acc2);
 }
 
 // ---------------------------------------------------------------------------------------------
-// Thermal RT, repwvl reduced-wavelength set: read_tau interpolation (repwvl_thermal.cpp:197-248)
+// Thermal RT, repwvl reduced-wavelength set, lane-pair layout (production kernel for repwvl):
+// read_tau's interpolation (repwvl_thermal.cpp:197-248) fused with radiative_transfer
+// (main.cpp:320-344, monochromatic Planck main.cpp:186-204); tau never touches HBM.
+// Same split as k_rt_lbl_pair: even lane = layers 0..9, odd lane = layers 19..10 of one wavelength.
+// ---------------------------------------------------------------------------------------------
+struct RepwvlPairLds {
+  double T[2][NH + 1];  // T[p][k] = Tlayer[layer(p,k)], k = NH: T_surface
+  double delT[2][NH], delP[2][NH], numDens[2][NH];
+  double vmr[2][RCM_NSPEC_REPWVL][NH];
+  int it[2][NH], ip[2][NH];
+};
+
+template <int CUBE>
+__global__ __launch_bounds__(64 * WPB, RCM_PAIR_LB) void k_rt_repwvl_pair(Dev d) {
+  __shared__ RepwvlPairLds s_col[WPB];
+  __shared__ double s_stage[WPB][NH + 1][64];
+  const int lane = threadIdx.x & 63;
+  const int wib = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int ncg = (d.ncol + WPB - 1) / WPB;
+  const int chunk = blockIdx.x / ncg;
+  const int colraw = (blockIdx.x - chunk * ncg) * WPB + wib;
+  const bool valid = colraw < d.ncol;
+  const int col = valid ? colraw : d.ncol - 1;
+  const int p = lane & 1;
+  RepwvlPairLds &s = s_col[wib];
+  double(*st)[64] = s_stage[wib];
+
+  // ---- column image: per (parity, position): temperature bracket of read_tau (:229-239)
+  if (lane < 2 * (NH + 1)) {
+    const int q = lane / (NH + 1), k = lane - q * (NH + 1);
+    if (k == NH) {
+      s.T[q][k] = d.Tsfc[col];
+    } else {
+      const int layer = q ? NL - 1 - k : k;
+      s.T[q][k] = d.T[(size_t)col * NL + layer];
+      const double midT = d.Ttau[(size_t)col * NL + layer];  // :217 (prop_at_Lev == 0)
+      const int ip = d.ip[layer];
+      const double tr = d.t_ref[ip];
+      const double *tp = d.t_pert;
+      const int it = lower_pos_dev([&](int j) { return tr + tp[j]; }, d.n_tpert, midT);  // :229-232
+      const double t0 = tr + tp[it], t1 = tr + tp[it + 1];
+      s.it[q][k] = it;
+      s.ip[q][k] = ip;
+      s.delT[q][k] = (midT - t0) / (t1 - t0);  // :239
+      s.delP[q][k] = d.delP[layer];
+      s.numDens[q][k] = d.numDens[layer];
+    }
+  }
+  for (int i = lane; i < 2 * RCM_NSPEC_REPWVL * NH; i += 64) {
+    const int q = i / (RCM_NSPEC_REPWVL * NH), r = i - q * (RCM_NSPEC_REPWVL * NH);
+    const int sp = r / NH, k = r - sp * NH;
+    const int layer = q ? NL - 1 - k : k;
+    s.vmr[q][sp][k] = d.gas[((size_t)col * RCM_NSPEC_REPWVL + sp) * NL + layer];
+  }
+  __syncthreads();
+
+  double acc1[NH + 1], acc2[NH];
+#pragma unroll
+  for (int j = 0; j <= NH; ++j) acc1[j] = 0.0;
+#pragma unroll
+  for (int j = 0; j < NH; ++j) acc2[j] = 0.0;
+
+  const int w0 = chunk * d.chunk_len;
+  const int w1 = min(w0 + d.chunk_len, d.nspec);
+  const int na = d.nangle;
+  const size_t ld = d.n_wvl;
+  const int cloud_k = p ? NL - 1 - d.cloud_layer : d.cloud_layer;
+
+  for (int w = w0 + (lane >> 1); w < w1; w += 32) {
+    // ---- optical depths of the lane's ten layers: bilinear (p,T) interpolation, :210-246
+    double tau[NH];
+#pragma unroll 1
+    for (int k = 0; k < NH; ++k) {
+      const int it = s.it[p][k], ip = s.ip[p][k];
+      const double delT = s.delT[p][k], delP = s.delP[p][k];
+      double a = 0.0;
+#pragma unroll
+      for (int sp = 0; sp < RCM_NSPEC_REPWVL; ++sp) {
+        if (!((d.species_mask >> sp) & 1u)) continue;  // vmr == 0 everywhere: the term is +0
+        const double *x0 = d.xsec + (((size_t)it * d.n_species + sp) * d.n_p + ip) * ld + w;
+        const double *x1 = d.xsec + (((size_t)(it + 1) * d.n_species + sp) * d.n_p + ip) * ld + w;
+        const double c0 = x0[0];                   // :235
+        const double cT = x1[0] - c0;              // :236
+        const double cP = x0[ld] - c0;             // :237
+        const double cPT = x1[ld] - cP - cT - c0;  // :238
+        const double xs = c0 + cT * delT + cP * delP + cPT * delT * delP;  // :241
+        a += xs * s.vmr[p][sp][k];                 // :244
+      }
+      a *= s.numDens[p][k];                        // :246
+      if (k == cloud_k) a += d.cloud_tau;          // main.cpp:266-274
+      st[k][lane] = clamp_tau(a);
+    }
+#pragma unroll
+    for (int k = 0; k < NH; ++k) tau[k] = st[k][lane];
+    // ---- monochromatic Planck * weight (main.cpp:186-204) for the lane's layers and the surface
+    const double pnum = d.pnum[w], lam5 = d.lam5[w], lkb = d.lkb[w];
+#pragma unroll 1
+    for (int k = 0; k <= NH; ++k) st[k][lane] = planck_mono(pnum, lam5, lkb, s.T[p][k]);
+    double B[NH];
+#pragma unroll
+    for (int k = 0; k < NH; ++k) B[k] = st[k][lane];
+    const double Linit = p ? st[NH][lane] : 0.0;
+
+    const int N = 2 * na - 1;
+    for (int n = N; CUBE ? 3 * n > N : n >= 1; n -= 2) {
+      const double a2 = -d.ang[(n - 1) >> 1], a1 = a2 * 0x1.71547652b82fep+0;
+      double t[NH];
+#pragma unroll
+      for (int k = 0; k < NH; ++k) t[k] = exp_trans(tau[k], a1, a2);  // main.cpp:209
+      pair_chain<CUBE ? 4 : 0>(d, t, B, Linit, n, acc1, acc2);
+    }
+  }
+  store_pair_partial(d, col, chunk, lane, valid, acc1, acc2);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Thermal RT, repwvl reduced-wavelength set (one lane per wavelength: reference variants): read_tau interpolation (repwvl_thermal.cpp:197-248)
 // fused with radiative_transfer (main.cpp:320-344, monochromatic Planck main.cpp:186-204).
 // tau never touches HBM.
 // ---------------------------------------------------------------------------------------------
@@ -764,10 +886,10 @@ int derive_repwvl_layers(rcm_ensemble *h) {
 }
 
 // Spectral chunking: ~16 rounds of the 2048 waves the chip holds at 2 waves/SIMD (a short tail and
-// room for the dispatcher), but never more chunks than 64-point rows.  Pure function of
+// room for the dispatcher), but never more chunks than 32-point rows.  Pure function of
 // (ncol, nspec, user override).
 void choose_chunks(int ncol, int nspec, int user_chunks, int *nchunk_out, int *chunk_len_out) {
-  const int rows = (nspec + 63) / 64;
+  const int rows = (nspec + 31) / 32;  // a lane-pair wave covers 32 spectral points per pass
   int nchunk;
   if (user_chunks > 0) {
     nchunk = user_chunks;
@@ -778,7 +900,7 @@ void choose_chunks(int ncol, int nspec, int user_chunks, int *nchunk_out, int *c
   if (nchunk > rows) nchunk = rows;
   if (nchunk < 1) nchunk = 1;
   const int rows_per_chunk = (rows + nchunk - 1) / nchunk;
-  *chunk_len_out = rows_per_chunk * 64;
+  *chunk_len_out = rows_per_chunk * 32;
   *nchunk_out = (rows + rows_per_chunk - 1) / rows_per_chunk;
 }
 
@@ -805,8 +927,11 @@ void launch_rt(rcm_ensemble *h, int blocks) {
     else
 #endif
       hipLaunchKernelGGL((rcm::k_rt_lbl<EXPV, CUBE, 1>), dim3(blocks), dim3(64 * rcm::WPB), 0, h->stream, h->d);
-  } else
+  } else if (EXPV == 1 && h->pair) {
+    hipLaunchKernelGGL((rcm::k_rt_repwvl_pair<CUBE>), dim3(blocks), dim3(64 * rcm::WPB), 0, h->stream, h->d);
+  } else {
     hipLaunchKernelGGL((rcm::k_rt_repwvl<EXPV, CUBE>), dim3(blocks), dim3(64 * rcm::WPB), 0, h->stream, h->d);
+  }
 }
 
 int launch_step(rcm_ensemble *h) {
