@@ -54,11 +54,32 @@ __device__ __forceinline__ double clamp_tau(double tau) { return fmin(fmax(tau, 
 #define RCM_EXP_LN2LO 0  // second FMA of the range reduction (k * low bits of ln2): |k| * 2.3e-17 relative, not needed
 #endif
 
+#ifndef RCM_EXP_BASE2
+#define RCM_EXP_BASE2 1  // 1: polynomial for 2^f in f = y - k directly (one instruction fewer)
+#endif
+
 __device__ __forceinline__ double exp_trans(double tau, double a1, double a2) {
   constexpr double kLn2Hi = 0x1.62e42fefa39efp-1;
   constexpr double kMagic = 0x1.8p+52;
   const double z = fma(tau, a1, kMagic);  // low word of z = k = rint(-tau*s*log2e), two's complement
   const double kf = z - kMagic;
+#if RCM_EXP_BASE2
+  // f = y - k with y = tau*a1 = -tau*s*log2(e): one FMA, exact up to the rounding of a1
+  // (relative 1.1e-16 of y: <= 4e-15 of the result wherever t >= 1e-15)
+  (void)a2;
+  (void)kLn2Hi;
+  const double f = fma(tau, a1, -kf);
+#if RCM_EXP_DEG == 9
+  double q = kExp2Poly9[9];
+#pragma unroll
+  for (int i = 8; i >= 0; --i) q = fma(q, f, kExp2Poly9[i]);
+#else
+  double q = kExp2Poly10[10];
+#pragma unroll
+  for (int i = 9; i >= 0; --i) q = fma(q, f, kExp2Poly10[i]);
+#endif
+  return __builtin_amdgcn_ldexp(q, __double2loint(z));
+#endif
   double r = fma(kf, -kLn2Hi, tau * a2);
 #if RCM_EXP_LN2LO
   r = fma(kf, -0x1.abc9e3b39803fp-56, r);

@@ -305,3 +305,16 @@ def test_driver_lbl_directory(pkg, olib, golden, tmp_path):
     T, th, tm = o.get_profile(0)
     want = [f"{i},{inp['cols']['player'][i]:f},{T[i]:f},{th[i]:f},{tm:f}" for i in range(20)]
     assert got[27:47] == want
+
+
+def test_config1_single_column_full_lbl_spectrum_against_oracle(pkg, olib, big):
+    # BASELINE.json configs[1]: one column, the full 131 071-band spectrum, fp64, GPU vs CPU.
+    # 2048 chunk partials are summed in chunk order by k_post; the oracle sums band by band.
+    inp = dict(big)
+    inp["ncol"] = 1
+    inp["cols"] = {k: (v[:1] if getattr(v, "ndim", 0) >= 1 and v.shape[0] == 8 else v) for k, v in big["cols"].items()}
+    g, o = H.gpu_ensemble(pkg, inp), H.oracle_ensemble(olib, inp, threads=1)
+    assert g.get_spectral_chunks() > 1000
+    g.step(2), o.step(2)
+    _check_fluxes(g, o, 1e-9)
+    _check_state(g, o)
