@@ -47,8 +47,8 @@ const char *rcm_last_error(void); /* thread-local, never NULL */
 
 /* ------------------------------------------------------------------------------------------
  * Ensemble life cycle.
- * nlayer must be 20 and nangle 30 or less... (main.cpp:78-80 compiles them in; kernels are
- * specialised for nlayer == 20, any 1 <= nangle <= 64).  `stream` is a hipStream_t passed as
+ * nlayer must be 20 (main.cpp:78-80 compiles 20 layers / 30 angles in; the kernels are specialised
+ * for nlayer == 20 and take any 1 <= nangle <= 64).  `stream` is a hipStream_t passed as
  * void* (e.g. torch.cuda.current_stream().cuda_stream); NULL makes the library create its own.
  * ------------------------------------------------------------------------------------------ */
 int rcm_create(int ncol, int nlayer, int nangle, int device, void *stream, rcm_ensemble **out);
@@ -62,6 +62,18 @@ int rcm_set_grid(rcm_ensemble *h, const double *plevel_hPa);
  * :341), the grey cloud of cloud_into_tau (main.cpp:266-274; cloud_layer 17, cloud_tau
  * tau_s/2 = 1.0).  cloud_layer = -1 disables the cloud. */
 int rcm_set_forcing(rcm_ensemble *h, double solar_irr, int cloud_layer, double cloud_tau);
+
+/* Per-column forcing: the same three quantities as arrays [ncol]; a NULL
+ * pointer leaves that quantity as it is.  cloud_layer[c] = -1 disables the cloud of column c. */
+int rcm_set_column_forcing(rcm_ensemble *h, const double *solar_irr, const int *cloud_layer,
+                           const double *cloud_tau);
+
+/* doubling_adding + solar_radiative_transfer_setup (main.cpp:214-264) on the device, one thread per
+ * column, for per-column tau_s[ncol], mu_s[ncol] (cosine of the solar zenith angle), albedo[ncol];
+ * sets each column's solar_irr and, as main.cpp:267 does, its cloud optical depth tau_s/2.
+ * solar_out (may be NULL) receives [ncol][7] = {r_dir, s_dir, t_dir, r, t, r_total, solar_irr}. */
+int rcm_solar_setup_columns(rcm_ensemble *h, const double *tau_s, const double *mu_s, const double *albedo,
+                            int doublings, double g_asym, double daytime, double E_0, double *solar_out);
 
 /* Replaces the table side of read_tau (repwvl_thermal.cpp:113-176): the datasets of a
  * Reduced*Forcing.nc file, xsec in FILE order [n_tpert][n_species][n_wvl][n_p].  The library
@@ -97,6 +109,25 @@ int rcm_set_columns(rcm_ensemble *h, const double *Tlayer0, const double *T_surf
  * The first ever step uses optical depths of the PRE-adjustment profile (main.cpp:500). */
 int rcm_step(rcm_ensemble *h, int nsteps);
 int rcm_sync(rcm_ensemble *h);
+
+/* The reference runs a fixed n_steps (main.cpp:83,531) and has no equilibrium criterion; this one is
+ * the build's: a column's residual is max_l |change of the convectively ADJUSTED
+ * profile| -- the Tlayer column output_conv prints -- between its last two iterations [K per step].
+ * (The raw step always moves the warmest-heated layer by max_dT = 5 K, main.cpp:156-162, and the
+ * model's top-of-atmosphere budget does not close, so neither can serve; the adjusted profile
+ * converges monotonically: 0.16 K/step after 50 steps, 2.7e-3 after 2000 for test.atm/Reduced10.)
+ * Steps `check_every` at a time until every column's residual is <= tol_K or max_steps have run.
+ * steps_done / residual_K (worst column) may be NULL. */
+int rcm_run_to_equilibrium(rcm_ensemble *h, double tol_K, int max_steps, int check_every, int *steps_done,
+                           double *residual_K);
+int rcm_get_residual(rcm_ensemble *h, double *resid /* [ncol] */);
+
+/* Binary restart file (the reference has no resume): step counter, Tlayer,
+ * T_surface, time, last timestep, gas block (H2O follows the feedback), rel_hum, forcing.  Load into a
+ * handle of the same ncol whose grid and spectral tables are already set; stepping on continues
+ * bit-identically. */
+int rcm_checkpoint_save(rcm_ensemble *h, const char *path);
+int rcm_checkpoint_load(rcm_ensemble *h, const char *path);
 
 /* State after the last step (post-thermodynamics, pre-adjustment, as main.cpp:583 leaves it).
  * Any output pointer may be NULL.  Tlayer [ncol][nlayer], T_surface/time_h/timestep [ncol]. */
@@ -159,6 +190,13 @@ int rcm_default_solar(double out[7]);
  * (malloc'd; free with rcm_free).  Returns the reference's codes: 0, -1 file not found,
  * -2 no memory, -5 not a rectangular matrix. */
 int rcm_ascii_file2xy2D(const char *path, int *nx, int *ny, double **x, double **y);
+
+/* One-time binary cache of the five lbl.xxx.asc tables, stored
+ * [species][layer][node] behind the wavelength nodes.  read returns the layout rcm_set_lbl_tables
+ * takes: wvl[n_nodes] and ONE block tabs[5][n_nodes][nlayer] (both malloc'd; rcm_free). */
+int rcm_lbl_cache_write(const char *path, int n_nodes, int nlayer, const double *wvl,
+                        const double *const tabs[RCM_NSPEC_LBL]);
+int rcm_lbl_cache_read(const char *path, int *n_nodes, int *nlayer, double **wvl, double **tabs);
 
 /* .rtab blob written by tools/flatten_repwvl.py (the datasets of a Reduced*Forcing.nc file).
  * dims = {n_tpert, n_species, n_wvl, n_p}; *blob (malloc'd; rcm_free) holds p_grid, t_ref,

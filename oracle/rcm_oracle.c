@@ -473,8 +473,8 @@ struct orc_ensemble {
   long long step_index; /* the reference's loop variable i (main.cpp:531) */
   double dp;
   double *plevel, *player, *conv;
-  double solar_irr, cloud_tau;
-  int cloud_layer;
+  double *solar_irr, *cloud_tau, *resid, *Tprev; /* per column */
+  int *cloud_layer;
   /* repwvl */
   int n_tpert, n_species, n_wvl, n_p;
   double *p_grid, *t_ref, *t_pert, *wvl, *weight, *xsec;
@@ -504,8 +504,15 @@ int orc_create(int ncol, int nlayer, int nangle, orc_ensemble **out) {
   h->mode = -1;
   h->nthreads = 1;
   h->dp = 1000.0 / (double)nlayer; /* main.cpp:355 */
-  h->cloud_layer = 17;
-  h->cloud_tau = 2.0 / 2.0; /* main.cpp:267 */
+  h->solar_irr = (double *)calloc(ncol, sizeof(double));
+  h->cloud_tau = (double *)calloc(ncol, sizeof(double));
+  h->cloud_layer = (int *)calloc(ncol, sizeof(int));
+  h->resid = (double *)calloc(ncol, sizeof(double));
+  h->Tprev = (double *)calloc((size_t)ncol * nlayer, sizeof(double));
+  for (int c = 0; c < ncol; ++c) {
+    h->cloud_layer[c] = 17;      /* main.cpp:92 */
+    h->cloud_tau[c] = 2.0 / 2.0; /* main.cpp:267 */
+  }
   h->T = (double *)calloc((size_t)ncol * nlayer, sizeof(double));
   h->Tsfc = (double *)calloc(ncol, sizeof(double));
   h->time_h = (float *)calloc(ncol, sizeof(float));
@@ -521,6 +528,7 @@ int orc_create(int ncol, int nlayer, int nangle, orc_ensemble **out) {
 int orc_destroy(orc_ensemble *h) {
   if (!h) return -1;
   free(h->plevel); free(h->player); free(h->conv);
+  free(h->solar_irr); free(h->cloud_tau); free(h->cloud_layer); free(h->resid); free(h->Tprev);
   free(h->p_grid); free(h->t_ref); free(h->t_pert); free(h->wvl); free(h->weight); free(h->xsec);
   free(h->lbl_wvl); free(h->h2o_ref);
   for (int s = 0; s < ORC_NSPEC_LBL; ++s) free(h->lbl_tab[s]);
@@ -545,9 +553,29 @@ int orc_set_grid(orc_ensemble *h, const double *plevel_hPa) {
 
 int orc_set_forcing(orc_ensemble *h, double solar_irr, int cloud_layer, double cloud_tau) {
   if (!h || cloud_layer < -1 || cloud_layer >= h->nlayer) return -1;
-  h->solar_irr = solar_irr;
-  h->cloud_layer = cloud_layer;
-  h->cloud_tau = cloud_tau;
+  for (int c = 0; c < h->ncol; ++c) {
+    h->solar_irr[c] = solar_irr;
+    h->cloud_layer[c] = cloud_layer;
+    h->cloud_tau[c] = cloud_tau;
+  }
+  return 0;
+}
+
+int orc_set_column_forcing(orc_ensemble *h, const double *solar_irr, const int *cloud_layer,
+                           const double *cloud_tau) {
+  if (!h) return -1;
+  for (int c = 0; c < h->ncol; ++c) {
+    if (cloud_layer && (cloud_layer[c] < -1 || cloud_layer[c] >= h->nlayer)) return -1;
+    if (solar_irr) h->solar_irr[c] = solar_irr[c];
+    if (cloud_layer) h->cloud_layer[c] = cloud_layer[c];
+    if (cloud_tau) h->cloud_tau[c] = cloud_tau[c];
+  }
+  return 0;
+}
+
+int orc_get_residual(orc_ensemble *h, double *resid) {
+  if (!h || !resid) return -1;
+  memcpy(resid, h->resid, h->ncol * sizeof(double));
   return 0;
 }
 
@@ -629,7 +657,7 @@ static void column_tau(const orc_ensemble *h, int c, double *tau) {
     orc_lbl_tau(h->n_nodes, nl, tabs, gas, tau);
     nspec = h->n_nodes - 1;
   }
-  if (h->cloud_layer >= 0) orc_cloud_into_tau(tau, nspec, nl, h->cloud_layer, h->cloud_tau);
+  if (h->cloud_layer[c] >= 0) orc_cloud_into_tau(tau, nspec, nl, h->cloud_layer[c], h->cloud_tau[c]);
 }
 
 /* H2O row of the gas block from relative humidity: main.cpp:562 */
@@ -668,16 +696,25 @@ int orc_step(orc_ensemble *h, int nsteps) {
       for (long long i = h->step_index; i < h->step_index + nsteps; ++i) { /* main.cpp:531 */
         if (i == 0) column_tau(h, c, tau); /* :500-504: first tau from the PRE-adjustment profile */
         orc_convective_adjustment(T, theta, h->conv, nl);                  /* :536-540 */
+        { /* equilibrium residual of the build (no reference counterpart): change of the adjusted profile */
+          double r = 0.0, *prev = h->Tprev + (size_t)c * nl;
+          for (int l = 0; l < nl; ++l) {
+            if (fabs(T[l] - prev[l]) > r) r = fabs(T[l] - prev[l]);
+            prev[l] = T[l];
+          }
+          h->resid[c] = (i == 0) ? 1e300 : r;
+        }
         if (i != 0) {                                                      /* :549 */
           column_feedback(h, c);                                           /* :562 */
           column_tau(h, c, tau);                                           /* :564-568 */
         }
         orc_radiative_transfer(nspec, nl, h->nangle, tau,
                                h->mode == ORC_MODE_REPWVL ? h->wvl : h->lbl_wvl, h->weight,
-                               h->mode == ORC_MODE_REPWVL ? 0 : 1, T, h->Tsfc[c], h->solar_irr,
+                               h->mode == ORC_MODE_REPWVL ? 0 : 1, T, h->Tsfc[c], h->solar_irr[c],
                                h->E_down + (size_t)c * nlev, h->E_up + (size_t)c * nlev,
                                h->dE + (size_t)c * nl);                    /* :574 */
         h->timestep[c] = orc_calculate_timestep(h->dp, h->dE + (size_t)c * nl, nl); /* :576 */
+
         orc_thermodynamics(T, nl, h->dp, h->dE + (size_t)c * nl, h->timestep[c], &h->Tsfc[c],
                            h->conv);                                       /* :578 */
         h->time_h[c] += (float)h->timestep[c] / 3600;                      /* :581 */

@@ -112,6 +112,9 @@ int orc_create(int ncol, int nlayer, int nangle, orc_ensemble **out);
 int orc_destroy(orc_ensemble *h);
 int orc_set_grid(orc_ensemble *h, const double *plevel_hPa);
 int orc_set_forcing(orc_ensemble *h, double solar_irr, int cloud_layer, double cloud_tau);
+int orc_set_column_forcing(orc_ensemble *h, const double *solar_irr, const int *cloud_layer,
+                           const double *cloud_tau);
+int orc_get_residual(orc_ensemble *h, double *resid);
 int orc_set_repwvl_tables(orc_ensemble *h, int n_tpert, int n_species, int n_wvl, int n_p,
                           const double *p_grid, const double *t_ref, const double *t_pert,
                           const double *wvl, const double *weight, const double *xsec);

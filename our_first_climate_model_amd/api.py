@@ -59,6 +59,14 @@ def lib():
     L.rcm_destroy.argtypes = [vp]
     L.rcm_set_grid.argtypes = [vp, _dp]
     L.rcm_set_forcing.argtypes = [vp, C.c_double, C.c_int, C.c_double]
+    L.rcm_set_column_forcing.argtypes = [vp, _dp, _ip, _dp]
+    L.rcm_solar_setup_columns.argtypes = [vp, _dp, _dp, _dp, C.c_int, C.c_double, C.c_double, C.c_double, _dp]
+    L.rcm_run_to_equilibrium.argtypes = [vp, C.c_double, C.c_int, C.c_int, _ip, _dp]
+    L.rcm_get_residual.argtypes = [vp, _dp]
+    L.rcm_checkpoint_save.argtypes = [vp, C.c_char_p]
+    L.rcm_checkpoint_load.argtypes = [vp, C.c_char_p]
+    L.rcm_lbl_cache_write.argtypes = [C.c_char_p, C.c_int, C.c_int, _dp, C.POINTER(_dp)]
+    L.rcm_lbl_cache_read.argtypes = [C.c_char_p, _ip, _ip, C.POINTER(_dp), C.POINTER(_dp)]
     L.rcm_set_repwvl_tables.argtypes = [vp] + [C.c_int] * 4 + [_dp] * 6
     L.rcm_set_lbl_tables.argtypes = [vp, C.c_int, _dp, C.POINTER(_dp), _dp]
     L.rcm_set_columns.argtypes = [vp] + [_dp] * 4
@@ -145,6 +153,26 @@ def ascii_file2xy2D(path):
     return 0, xs, ys
 
 
+def lbl_cache_write(path, wvl, tabs):
+    """One-time binary cache of the five lbl tables (rcm_lbl_cache_write)."""
+    wvl = _f64(wvl)
+    tabs = [_f64(t) for t in tabs]
+    arr = (_dp * NSPEC_LBL)(*[_p(t) for t in tabs])
+    _ck(lib().rcm_lbl_cache_write(os.fsencode(path), wvl.size, tabs[0].shape[1], _p(wvl), arr))
+
+
+def lbl_cache_read(path):
+    """Returns (wvl[n], [5 tables of shape (n, nlayer)])."""
+    n, nl = C.c_int(0), C.c_int(0)
+    w, t = _dp(), _dp()
+    _ck(lib().rcm_lbl_cache_read(os.fsencode(path), C.byref(n), C.byref(nl), C.byref(w), C.byref(t)))
+    wvl = np.ctypeslib.as_array(w, (n.value,)).copy()
+    tabs = np.ctypeslib.as_array(t, (NSPEC_LBL, n.value, nl.value)).copy()
+    lib().rcm_free(w)
+    lib().rcm_free(t)
+    return wvl, [tabs[s] for s in range(NSPEC_LBL)]
+
+
 def read_rtab(path):
     """The datasets of a flattened Reduced*Forcing.nc (tools/flatten_repwvl.py) via rcm_rtab_load."""
     dims = (C.c_longlong * 4)()
@@ -205,6 +233,38 @@ class Ensemble:
 
     def set_forcing(self, solar_irr, cloud_layer=17, cloud_tau=1.0):
         _ck(lib().rcm_set_forcing(self.h, solar_irr, cloud_layer, cloud_tau))
+
+    def set_column_forcing(self, solar_irr=None, cloud_layer=None, cloud_tau=None):
+        a = None if solar_irr is None else _f64(solar_irr, (self.ncol,), "solar_irr")
+        b = None if cloud_layer is None else np.ascontiguousarray(cloud_layer, dtype=np.int32)
+        c = None if cloud_tau is None else _f64(cloud_tau, (self.ncol,), "cloud_tau")
+        if b is not None and b.shape != (self.ncol,):
+            raise ValueError("cloud_layer: expected shape (ncol,)")
+        _ck(lib().rcm_set_column_forcing(self.h, _p(a), None if b is None else b.ctypes.data_as(_ip), _p(c)))
+
+    def solar_setup_columns(self, tau_s, mu_s, albedo, doublings=20, g_asym=0.85, daytime=0.5, E_0=1361.0):
+        """main.cpp:214-264 on the device per column; returns [ncol][7] (r_dir, s_dir, t_dir, r, t, r_total,
+        solar_irr) and installs solar_irr and cloud_tau = tau_s/2 (main.cpp:267) per column."""
+        out = np.zeros((self.ncol, 7))
+        _ck(lib().rcm_solar_setup_columns(self.h, _p(_f64(tau_s, (self.ncol,))), _p(_f64(mu_s, (self.ncol,))),
+                                          _p(_f64(albedo, (self.ncol,))), doublings, g_asym, daytime, E_0, _p(out)))
+        return out
+
+    def get_residual(self):
+        r = np.zeros(self.ncol)
+        _ck(lib().rcm_get_residual(self.h, _p(r)))
+        return r
+
+    def run_to_equilibrium(self, tol_K, max_steps, check_every=10):
+        done, worst = C.c_int(0), C.c_double(0)
+        _ck(lib().rcm_run_to_equilibrium(self.h, tol_K, max_steps, check_every, C.byref(done), C.byref(worst)))
+        return done.value, worst.value
+
+    def checkpoint_save(self, path):
+        _ck(lib().rcm_checkpoint_save(self.h, os.fsencode(path)))
+
+    def checkpoint_load(self, path):
+        _ck(lib().rcm_checkpoint_load(self.h, os.fsencode(path)))
 
     def set_repwvl_tables(self, t):
         arrs = [_f64(t[k]) for k in ("p_grid", "t_ref", "t_pert", "wvl", "weight", "xsec")]

@@ -246,6 +246,65 @@ int rcm_rtab_load(const char *path, long long dims[4], double **blob) {
 }
 
 // ---------------------------------------------------------------------------------------------
+// Binary cache of the lbl tables: "LBLTAB1\0", int64 n_nodes, int64 nlayer, wvl[n_nodes],
+// tab[5][nlayer][n_nodes] (node fastest).
+// ---------------------------------------------------------------------------------------------
+int rcm_lbl_cache_write(const char *path, int n_nodes, int nlayer, const double *wvl,
+                        const double *const tabs[RCM_NSPEC_LBL]) {
+  if (!path || !wvl || !tabs || n_nodes < 2 || nlayer < 1) return fail(RCM_ERR_ARG, "rcm_lbl_cache_write: bad argument");
+  for (int s = 0; s < RCM_NSPEC_LBL; ++s)
+    if (!tabs[s]) return fail(RCM_ERR_ARG, "rcm_lbl_cache_write: NULL table");
+  FILE *f = std::fopen(path, "wb");
+  if (!f) return fail(RCM_ERR_IO, std::string("rcm_lbl_cache_write: cannot open ") + path);
+  const long long dims[2] = {n_nodes, nlayer};
+  bool ok = std::fwrite("LBLTAB1", 1, 8, f) == 8 && std::fwrite(dims, sizeof(long long), 2, f) == 2 &&
+            std::fwrite(wvl, sizeof(double), (size_t)n_nodes, f) == (size_t)n_nodes;
+  std::vector<double> row((size_t)n_nodes);
+  for (int s = 0; ok && s < RCM_NSPEC_LBL; ++s)
+    for (int l = 0; ok && l < nlayer; ++l) {
+      for (int b = 0; b < n_nodes; ++b) row[b] = tabs[s][(size_t)b * nlayer + l];
+      ok = std::fwrite(row.data(), sizeof(double), (size_t)n_nodes, f) == (size_t)n_nodes;
+    }
+  ok = (std::fclose(f) == 0) && ok;
+  return ok ? RCM_OK : fail(RCM_ERR_IO, std::string("rcm_lbl_cache_write: write failed: ") + path);
+}
+
+int rcm_lbl_cache_read(const char *path, int *n_nodes, int *nlayer, double **wvl, double **tabs) {
+  if (!path || !n_nodes || !nlayer || !wvl || !tabs) return fail(RCM_ERR_ARG, "rcm_lbl_cache_read: bad argument");
+  FILE *f = std::fopen(path, "rb");
+  if (!f) return fail(RCM_ERR_IO, std::string("rcm_lbl_cache_read: cannot open ") + path);
+  char magic[8];
+  long long dims[2];
+  if (std::fread(magic, 1, 8, f) != 8 || std::memcmp(magic, "LBLTAB1", 8) != 0 ||
+      std::fread(dims, sizeof(long long), 2, f) != 2 || dims[0] < 2 || dims[0] > (1LL << 28) || dims[1] < 1 ||
+      dims[1] > 4096) {
+    std::fclose(f);
+    return fail(RCM_ERR_FORMAT, std::string("rcm_lbl_cache_read: not an LBLTAB1 file: ") + path);
+  }
+  const size_t n = (size_t)dims[0], nl = (size_t)dims[1];
+  double *w = (double *)std::malloc(n * sizeof(double));
+  double *t = (double *)std::malloc((size_t)RCM_NSPEC_LBL * n * nl * sizeof(double));
+  std::vector<double> row(n);
+  bool ok = w && t && std::fread(w, sizeof(double), n, f) == n;
+  for (size_t s = 0; ok && s < RCM_NSPEC_LBL; ++s)
+    for (size_t l = 0; ok && l < nl; ++l) {
+      ok = std::fread(row.data(), sizeof(double), n, f) == n;
+      for (size_t b = 0; ok && b < n; ++b) t[(s * n + b) * nl + l] = row[b];
+    }
+  std::fclose(f);
+  if (!ok) {
+    std::free(w);
+    std::free(t);
+    return fail(w && t ? RCM_ERR_FORMAT : RCM_ERR_NOMEM, std::string("rcm_lbl_cache_read: truncated or out of memory: ") + path);
+  }
+  *n_nodes = (int)n;
+  *nlayer = (int)nl;
+  *wvl = w;
+  *tabs = t;
+  return RCM_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
 // output.txt formats: main.cpp:513-519, 528 (banner) and :109-110 (rows).
 // ---------------------------------------------------------------------------------------------
 int rcm_write_banner(void *fp, double tau_s, double mu_s, const double solar[7]) {

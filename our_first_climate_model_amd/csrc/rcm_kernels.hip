@@ -50,8 +50,14 @@ struct Dev {
   int nspec;      // spectral points: n_wvl (repwvl) or bands = n_nodes-1 (lbl)
   int nchunk;     // spectral chunks per column
   int chunk_len;  // points per chunk (multiple of 32)
-  int cloud_layer;
-  double cloud_tau, solar_irr, dp, sigdpi;
+  double dp, sigdpi;
+  // per-column forcing (rcm_set_forcing fills them uniformly): solar heating of the lowest layer
+  // (main.cpp:341), grey cloud layer index (-1: none) and optical depth (main.cpp:266-274)
+  const double *solar_irr, *cloud_tau;
+  const int *cloud_layer;
+  double *resid;  // equilibrium residual per column: max_l |change of the ADJUSTED profile| between the
+                  // last two iterations [K] (1e300 until two iterations have run)
+  double *Tprev;  // adjusted profile of the previous iteration
   const double *player, *conv, *ang;  // ang = [inv_mu[nangle], cw[nangle]]
   double *T, *Ttau, *Tsfc, *dt, *gas, *E_down, *E_up, *dE, *partial;
   const double *rel_hum;
@@ -170,12 +176,13 @@ __device__ __forceinline__ void store_partial(const Dev &d, int col, int chunk, 
 // tau_l = sum_s scale[s][l] * tab_s[b][l] (+ grey cloud, main.cpp:266-274).
 // sc = the column's [5][NL] multipliers in LDS.
 // ---------------------------------------------------------------------------------------------
-__device__ __forceinline__ double lbl_tau_layer(const Dev &d, const double *sc, long b, int l) {
+__device__ __forceinline__ double lbl_tau_layer(const Dev &d, const double *sc, long b, int l, int cloud_layer,
+                                                double cloud_tau) {
   double acc = 0.0;
 #pragma unroll
   for (int s = 0; s < RCM_NSPEC_LBL; ++s)
     acc = fma(sc[s * NL + l], d.lbl_tab[(size_t)(s * NL + l) * d.lbl_ld + b], acc);
-  if (l == d.cloud_layer) acc += d.cloud_tau;
+  if (l == cloud_layer) acc += cloud_tau;
   return acc;
 }
 
@@ -208,7 +215,8 @@ __device__ __forceinline__ void repwvl_prologue(const Dev &d, int col, int lane,
 }
 
 // One layer of read_tau's interpolation for the lane's wavelength (:210-246).
-__device__ __forceinline__ double repwvl_tau_layer(const Dev &d, const RepwvlLds &s, int w, int l) {
+__device__ __forceinline__ double repwvl_tau_layer(const Dev &d, const RepwvlLds &s, int w, int l, int cloud_layer,
+                                                   double cloud_tau) {
   const size_t ld = d.n_wvl;
   const int it = s.it[l], ip = d.ip[l];
   const double delT = s.delT[l], delP = d.delP[l];
@@ -226,7 +234,7 @@ __device__ __forceinline__ double repwvl_tau_layer(const Dev &d, const RepwvlLds
     acc += xs * s.vmr[sp * NL + l];               // :244
   }
   acc *= d.numDens[l];                            // :246
-  if (l == d.cloud_layer) acc += d.cloud_tau;     // main.cpp:266-274
+  if (l == cloud_layer) acc += cloud_tau;         // main.cpp:266-274
   return acc;
 }
 
@@ -252,6 +260,8 @@ __global__ __launch_bounds__(64 * WPB, RCM_LB) void k_rt_lbl(Dev d) {
   // LDS: [0..19] Tlayer, [20] T_surface, [21..41] sigdpi*T^4, [48..147] gas multipliers [5][20],
   //      [150..170] sigdpi*T^4*conc, [171..191] 1/T
   double *sc = s_col[wib];
+  const int cloud_layer = d.cloud_layer[col];
+  const double cloud_tau = d.cloud_tau[col];
   if (lane < NL) sc[lane] = d.T[(size_t)col * NL + lane];
   if (lane == NL) sc[NL] = d.Tsfc[col];
   for (int i = lane; i < RCM_NSPEC_LBL * NL; i += 64) sc[48 + i] = d.gas[(size_t)col * RCM_NSPEC_LBL * NL + i];
@@ -275,7 +285,7 @@ __global__ __launch_bounds__(64 * WPB, RCM_LB) void k_rt_lbl(Dev d) {
   for (long b = b0 + lane; b < b1; b += 64) {  // main.cpp:329, lanes over spectral points
     double tau[NL];
 #pragma unroll 4
-    for (int l = 0; l < NL; ++l) st[l][lane] = lbl_tau_layer(d, sc + 48, b, l);
+    for (int l = 0; l < NL; ++l) st[l][lane] = lbl_tau_layer(d, sc + 48, b, l, cloud_layer, cloud_tau);
 #pragma unroll
     for (int l = 0; l < NL; ++l) tau[l] = EXPV ? clamp_tau(st[l][lane]) : st[l][lane];
     const double wnumhi = 1.0E7 / d.lbl_wvl[b];      // cplkavg.cpp:141
@@ -430,7 +440,9 @@ __global__ __launch_bounds__(64 * WPB, RCM_PAIR_LB) void k_rt_lbl_pair(Dev d) {
   // the lane's first table row and the row step: layers 0,1,.. (even) or 19,18,.. (odd)
   const double *row0 = d.lbl_tab + (size_t)(p ? NL - 1 : 0) * d.lbl_ld;
   const long rstep = p ? -d.lbl_ld : d.lbl_ld;
-  const int cloud_k = p ? NL - 1 - d.cloud_layer : d.cloud_layer;  // position of the cloud layer, if < NH
+  const int cloud_layer = d.cloud_layer[col];
+  const double cloud_tau = d.cloud_tau[col];
+  const int cloud_k = p ? NL - 1 - cloud_layer : cloud_layer;  // position of the cloud layer, if in [0, NH)
 
   for (long b = b0 + (lane >> 1); b < b1; b += 32) {  // main.cpp:329: 32 bands per wave pass
     // ---- optical depths of the lane's ten layers (lbl composition + cloud, main.cpp:266-274)
@@ -442,7 +454,7 @@ __global__ __launch_bounds__(64 * WPB, RCM_PAIR_LB) void k_rt_lbl_pair(Dev d) {
         double a = 0.0;
 #pragma unroll
         for (int sp = 0; sp < RCM_NSPEC_LBL; ++sp) a = fma(s.gas[p][sp][k], rp[(size_t)sp * NL * d.lbl_ld], a);
-        if (k == cloud_k) a += d.cloud_tau;
+        if (k == cloud_k) a += cloud_tau;
         st[k][lane] = clamp_tau(a);
       }
 #pragma unroll
@@ -546,7 +558,9 @@ __global__ __launch_bounds__(64 * WPB, RCM_PAIR_LB) void k_rt_repwvl_pair(Dev d)
   const int w1 = min(w0 + d.chunk_len, d.nspec);
   const int na = d.nangle;
   const size_t ld = d.n_wvl;
-  const int cloud_k = p ? NL - 1 - d.cloud_layer : d.cloud_layer;
+  const int cloud_layer = d.cloud_layer[col];
+  const double cloud_tau = d.cloud_tau[col];
+  const int cloud_k = p ? NL - 1 - cloud_layer : cloud_layer;
 
   for (int w = w0 + (lane >> 1); w < w1; w += 32) {
     // ---- optical depths of the lane's ten layers: bilinear (p,T) interpolation, :210-246
@@ -569,7 +583,7 @@ __global__ __launch_bounds__(64 * WPB, RCM_PAIR_LB) void k_rt_repwvl_pair(Dev d)
         a += xs * s.vmr[p][sp][k];                 // :244
       }
       a *= s.numDens[p][k];                        // :246
-      if (k == cloud_k) a += d.cloud_tau;          // main.cpp:266-274
+      if (k == cloud_k) a += cloud_tau;            // main.cpp:266-274
       st[k][lane] = clamp_tau(a);
     }
 #pragma unroll
@@ -625,7 +639,7 @@ __global__ __launch_bounds__(64 * WPB, 2) void k_rt_repwvl(Dev d) {
   for (int w = w0 + lane; w < w1; w += 64) {
     double tau[NL];
 #pragma unroll 1
-    for (int l = 0; l < NL; ++l) st[l][lane] = repwvl_tau_layer(d, s, w, l);
+    for (int l = 0; l < NL; ++l) st[l][lane] = repwvl_tau_layer(d, s, w, l, d.cloud_layer[col], d.cloud_tau[col]);
 #pragma unroll
     for (int l = 0; l < NL; ++l) tau[l] = EXPV ? clamp_tau(st[l][lane]) : st[l][lane];
     const double pnum = d.pnum[w], lam5 = d.lam5[w], lkb = d.lkb[w];
@@ -669,8 +683,14 @@ __global__ void k_pre(Dev d, int first) {
     for (int i = 0; i < NL; ++i) d.Ttau[(size_t)c * NL + i] = T[i];
   }
   adjust(d.conv, T, th);
+  double resid = 0.0;
 #pragma unroll
-  for (int i = 0; i < NL; ++i) d.T[(size_t)c * NL + i] = T[i];
+  for (int i = 0; i < NL; ++i) {
+    d.T[(size_t)c * NL + i] = T[i];
+    resid = fmax(resid, fabs(T[i] - d.Tprev[(size_t)c * NL + i]));
+    d.Tprev[(size_t)c * NL + i] = T[i];
+  }
+  d.resid[c] = first ? 1e300 : resid;
   if (!first) {
     double *gas = d.gas + (size_t)c * d.ngas * NL;
 #pragma unroll
@@ -708,7 +728,7 @@ __global__ __launch_bounds__(64) void k_post(Dev d) {
   double dE[NL];
 #pragma unroll
   for (int i = 0; i < NL; ++i) dE[i] = Ed[i] - Ed[i + 1] + Eu[i + 1] - Eu[i];  // main.cpp:338
-  dE[NL - 1] += d.solar_irr + Ed[NL] - Eu[NL];                                  // main.cpp:341
+  dE[NL - 1] += d.solar_irr[c] + Ed[NL] - Eu[NL];                               // main.cpp:341
   double mx = dE[0];
 #pragma unroll
   for (int i = 1; i < NL; ++i) mx = (mx < dE[i]) ? dE[i] : mx;  // signed max_element, main.cpp:157
@@ -757,10 +777,43 @@ __global__ __launch_bounds__(64) void k_tau(Dev d, int col, double *out) {
   if (p >= d.nspec) return;
   if (d.mode == MODE_REPWVL) {
 #pragma unroll 1
-    for (int l = 0; l < NL; ++l) out[(size_t)p * NL + l] = repwvl_tau_layer(d, s, (int)p, l);
+    for (int l = 0; l < NL; ++l)
+      out[(size_t)p * NL + l] = repwvl_tau_layer(d, s, (int)p, l, d.cloud_layer[col], d.cloud_tau[col]);
   } else {
 #pragma unroll 4
-    for (int l = 0; l < NL; ++l) out[(size_t)p * NL + l] = lbl_tau_layer(d, s_scale, p, l);
+    for (int l = 0; l < NL; ++l)
+      out[(size_t)p * NL + l] = lbl_tau_layer(d, s_scale, p, l, d.cloud_layer[col], d.cloud_tau[col]);
+  }
+}
+
+// doubling_adding + solar_radiative_transfer_setup (main.cpp:214-264), one thread per column:
+// per-column optical thickness, cosine of the solar zenith angle and surface albedo.  Also sets the
+// column's cloud optical depth to tau_s/2 as main.cpp:267 does.  out = [ncol][7] (may be null).
+__global__ void k_solar(int ncol, const double *tau_s, const double *mu_s, const double *albedo, int doublings,
+                        double g_asym, double daytime, double E_0, double *solar_irr, double *cloud_tau,
+                        double *out) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= ncol) return;
+  const double mu = mu_s[c];
+  double dtau = (1 - g_asym) * tau_s[c] / pow(2.0, (double)doublings);  // main.cpp:216-217
+  double r = 0.5 * dtau / mu, t = 1.0 - r;                              // main.cpp:223-224
+  double r_dir = dtau / mu * 0.5, s_dir = r_dir, t_dir = 1 - dtau / mu;  // main.cpp:225-227
+  for (int i = 0; i < doublings; ++i) {                                  // main.cpp:232-250
+    const double den = 1 - r * r;
+    const double r2 = r + (r * t * t) / den;
+    const double t2 = (t * t) / den;
+    const double td2 = t_dir * t_dir;
+    const double sd2 = (t * s_dir + t_dir * r_dir * r * t) / den + t_dir * s_dir;
+    const double rd2 = (t * s_dir * r + t * t_dir * r) / den + r_dir;
+    r = r2, t = t2, t_dir = td2, s_dir = sd2, r_dir = rd2;
+  }
+  const double r_total = r_dir + (t_dir + s_dir) / (1 - albedo[c] * r) * t * albedo[c];  // main.cpp:258
+  const double irr = daytime * E_0 * mu * (1 - r_total);                                 // main.cpp:260
+  solar_irr[c] = irr;
+  cloud_tau[c] = tau_s[c] / 2.0;  // main.cpp:267
+  if (out) {
+    double *o = out + (size_t)c * 7;
+    o[0] = r_dir, o[1] = s_dir, o[2] = t_dir, o[3] = r, o[4] = t, o[5] = r_total, o[6] = irr;
   }
 }
 
@@ -977,6 +1030,26 @@ int launch_step(rcm_ensemble *h) {
 
 }  // namespace
 
+// ---- restart file: "RCMCKPT1", int64 {ncol, nlayer, ngas, mode, step_index}, then the arrays ----
+namespace {
+struct CkptField {
+  void *dev;
+  size_t bytes;
+};
+std::vector<CkptField> ckpt_fields(rcm_ensemble *h) {
+  const Dev &d = h->d;
+  const size_t nc = (size_t)h->ncol, nT = nc * NL;
+  return {{d.T, nT * 8},           {d.Ttau, nT * 8},
+          {d.Tsfc, nc * 8},        {d.dt, nc * 8},
+          {d.time_h, nc * 4},      {d.gas, nT * d.ngas * 8},
+          {(void *)d.rel_hum, nT * 8}, {(void *)d.solar_irr, nc * 8},
+          {(void *)d.cloud_tau, nc * 8}, {(void *)d.cloud_layer, nc * 4},
+          {d.E_down, nc * NLEV * 8}, {d.E_up, nc * NLEV * 8},
+          {d.dE, nT * 8},          {d.resid, nc * 8},
+          {d.Tprev, nT * 8}};
+}
+}  // namespace
+
 extern "C" {
 
 int rcm_create(int ncol, int nlayer, int nangle, int device, void *stream, rcm_ensemble **out) {
@@ -1011,9 +1084,6 @@ int rcm_create(int ncol, int nlayer, int nangle, int device, void *stream, rcm_e
   }
   Dev &d = h->d;
   d.ncol = ncol, d.nangle = nangle, d.mode = rcm::MODE_NONE;
-  d.cloud_layer = 17;       // main.cpp:92
-  d.cloud_tau = 2.0 / 2.0;  // tau_s / 2, main.cpp:86,267
-  d.solar_irr = 0.0;
   d.dp = 1000.0 / (double)nlayer;  // main.cpp:355
   d.sigdpi = 5.67032E-8 / M_PI;    // cplkavg.cpp:121,134
   const size_t nT = (size_t)ncol * NL, nE = (size_t)ncol * NLEV;
@@ -1028,6 +1098,11 @@ int rcm_create(int ncol, int nlayer, int nangle, int device, void *stream, rcm_e
   rc = rc ? rc : dev_alloc(h, &d.E_up, nE);
   rc = rc ? rc : dev_alloc(h, &d.dE, nT);
   rc = rc ? rc : dev_alloc(h, &h->scratch, (size_t)2 * NL);
+  rc = rc ? rc : dev_alloc(h, (double **)&d.solar_irr, (size_t)ncol);
+  rc = rc ? rc : dev_alloc(h, (double **)&d.cloud_tau, (size_t)ncol);
+  rc = rc ? rc : dev_alloc(h, (int **)&d.cloud_layer, (size_t)ncol);
+  rc = rc ? rc : dev_alloc(h, &d.resid, (size_t)ncol);
+  rc = rc ? rc : dev_alloc(h, &d.Tprev, nT);
   rc = rc ? rc : dev_alloc(h, (double **)&d.player, (size_t)NL);
   rc = rc ? rc : dev_alloc(h, (double **)&d.conv, (size_t)NL);
   rc = rc ? rc : dev_alloc(h, &h->d_ip, (size_t)NL);
@@ -1049,8 +1124,13 @@ int rcm_create(int ncol, int nlayer, int nangle, int device, void *stream, rcm_e
   if (me == hipSuccess) me = hipMemsetAsync(d.E_down, 0, nE * sizeof(double), h->stream);
   if (me == hipSuccess) me = hipMemsetAsync(d.E_up, 0, nE * sizeof(double), h->stream);
   if (me == hipSuccess) me = hipMemsetAsync(d.dE, 0, nT * sizeof(double), h->stream);
+  if (me == hipSuccess) me = hipMemsetAsync(d.resid, 0, ncol * sizeof(double), h->stream);
+  if (me == hipSuccess) me = hipMemsetAsync(d.Tprev, 0, nT * sizeof(double), h->stream);
   if (me == hipSuccess) me = hipStreamSynchronize(h->stream);
   if (me != hipSuccess) return bail(fail(RCM_ERR_HIP, std::string("rcm_create: ") + hipGetErrorString(me)));
+  // the reference's compiled-in forcing until the caller says otherwise: cloud in layer 17 with
+  // tau_s/2 = 1.0 (main.cpp:86,92,267), solar heating 0
+  if ((rc = rcm_set_forcing(h, 0.0, 17, 2.0 / 2.0))) return bail(rc);
   *out = h;
   return RCM_OK;
 }
@@ -1090,9 +1170,84 @@ int rcm_set_grid(rcm_ensemble *h, const double *plevel_hPa) {
 
 int rcm_set_forcing(rcm_ensemble *h, double solar_irr, int cloud_layer, double cloud_tau) {
   if (!h || cloud_layer < -1 || cloud_layer >= NL) return fail(RCM_ERR_ARG, "rcm_set_forcing: bad argument");
-  h->d.solar_irr = solar_irr;
-  h->d.cloud_layer = cloud_layer;
-  h->d.cloud_tau = cloud_tau;
+  if (int rc = use_device(h)) return rc;
+  std::vector<double> a((size_t)h->ncol, solar_irr), b((size_t)h->ncol, cloud_tau);
+  std::vector<int> c((size_t)h->ncol, cloud_layer);
+  return rcm_set_column_forcing(h, a.data(), c.data(), b.data());
+}
+
+int rcm_set_column_forcing(rcm_ensemble *h, const double *solar_irr, const int *cloud_layer, const double *cloud_tau) {
+  if (!h) return fail(RCM_ERR_ARG, "rcm_set_column_forcing: NULL handle");
+  if (cloud_layer)
+    for (int c = 0; c < h->ncol; ++c)
+      if (cloud_layer[c] < -1 || cloud_layer[c] >= NL)
+        return fail(RCM_ERR_ARG, "rcm_set_column_forcing: cloud_layer must be in -1..nlayer-1");
+  if (int rc = use_device(h)) return rc;
+  const size_t n = (size_t)h->ncol;
+  if (solar_irr)
+    HIPCK(hipMemcpyAsync((void *)h->d.solar_irr, solar_irr, n * sizeof(double), hipMemcpyHostToDevice, h->stream));
+  if (cloud_layer)
+    HIPCK(hipMemcpyAsync((void *)h->d.cloud_layer, cloud_layer, n * sizeof(int), hipMemcpyHostToDevice, h->stream));
+  if (cloud_tau)
+    HIPCK(hipMemcpyAsync((void *)h->d.cloud_tau, cloud_tau, n * sizeof(double), hipMemcpyHostToDevice, h->stream));
+  HIPCK(hipStreamSynchronize(h->stream));
+  return RCM_OK;
+}
+
+int rcm_solar_setup_columns(rcm_ensemble *h, const double *tau_s, const double *mu_s, const double *albedo,
+                            int doublings, double g_asym, double daytime, double E_0, double *solar_out) {
+  if (!h || !tau_s || !mu_s || !albedo || doublings < 0)
+    return fail(RCM_ERR_ARG, "rcm_solar_setup_columns: bad argument");
+  for (int c = 0; c < h->ncol; ++c)
+    if (!(mu_s[c] > 0)) return fail(RCM_ERR_ARG, "rcm_solar_setup_columns: mu_s must be positive");
+  if (int rc = use_device(h)) return rc;
+  const size_t n = (size_t)h->ncol;
+  double *buf = nullptr;
+  HIPCK(hipMalloc((void **)&buf, n * 10 * sizeof(double)));
+  double *d_tau = buf, *d_mu = buf + n, *d_alb = buf + 2 * n, *d_out = buf + 3 * n;
+  hipError_t e = hipMemcpyAsync(d_tau, tau_s, n * sizeof(double), hipMemcpyHostToDevice, h->stream);
+  if (e == hipSuccess) e = hipMemcpyAsync(d_mu, mu_s, n * sizeof(double), hipMemcpyHostToDevice, h->stream);
+  if (e == hipSuccess) e = hipMemcpyAsync(d_alb, albedo, n * sizeof(double), hipMemcpyHostToDevice, h->stream);
+  if (e == hipSuccess) {
+    hipLaunchKernelGGL(rcm::k_solar, dim3((unsigned)((n + 127) / 128)), dim3(128), 0, h->stream, h->ncol, d_tau, d_mu,
+                       d_alb, doublings, g_asym, daytime, E_0, (double *)h->d.solar_irr, (double *)h->d.cloud_tau,
+                       d_out);
+    e = hipGetLastError();
+  }
+  if (e == hipSuccess && solar_out)
+    e = hipMemcpyAsync(solar_out, d_out, n * 7 * sizeof(double), hipMemcpyDeviceToHost, h->stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+  (void)hipFree(buf);
+  if (e != hipSuccess) return fail(RCM_ERR_HIP, std::string("rcm_solar_setup_columns: ") + hipGetErrorString(e));
+  return RCM_OK;
+}
+
+int rcm_get_residual(rcm_ensemble *h, double *resid) {
+  if (!h || !resid) return fail(RCM_ERR_ARG, "rcm_get_residual: bad argument");
+  if (int rc = use_device(h)) return rc;
+  HIPCK(hipMemcpyAsync(resid, h->d.resid, (size_t)h->ncol * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  HIPCK(hipStreamSynchronize(h->stream));
+  return RCM_OK;
+}
+
+int rcm_run_to_equilibrium(rcm_ensemble *h, double tol_K, int max_steps, int check_every, int *steps_done,
+                           double *residual_K) {
+  if (!h || !(tol_K >= 0) || max_steps < 0 || check_every < 1)
+    return fail(RCM_ERR_ARG, "rcm_run_to_equilibrium: bad argument");
+  std::vector<double> r((size_t)h->ncol);
+  int done = 0;
+  double worst = HUGE_VAL;
+  while (done < max_steps) {
+    const int n = std::min(check_every, max_steps - done);
+    if (int rc = rcm_step(h, n)) return rc;
+    done += n;
+    if (int rc = rcm_get_residual(h, r.data())) return rc;
+    worst = 0.0;
+    for (double v : r) worst = (v > worst || v != v) ? v : worst;
+    if (worst <= tol_K) break;
+  }
+  if (steps_done) *steps_done = done;
+  if (residual_K) *residual_K = worst;
   return RCM_OK;
 }
 
@@ -1332,6 +1487,73 @@ int rcm_pack_state(rcm_ensemble *h, void *dev_out) {
   const size_t n = (size_t)h->ncol * NLEV;
   hipLaunchKernelGGL(rcm::k_pack, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, h->stream, h->d, (double *)dev_out);
   HIPCK(hipGetLastError());
+  return RCM_OK;
+}
+
+int rcm_checkpoint_save(rcm_ensemble *h, const char *path) {
+  if (!h || !path) return fail(RCM_ERR_ARG, "rcm_checkpoint_save: bad argument");
+  if (!h->have_columns) return fail(RCM_ERR_STATE, "rcm_checkpoint_save: columns not set");
+  if (int rc = use_device(h)) return rc;
+  FILE *f = std::fopen(path, "wb");
+  if (!f) return fail(RCM_ERR_IO, std::string("rcm_checkpoint_save: cannot open ") + path);
+  const long long hdr[5] = {h->ncol, NL, h->d.ngas, h->mode, h->step_index};
+  bool ok = std::fwrite("RCMCKPT1", 1, 8, f) == 8 && std::fwrite(hdr, sizeof(long long), 5, f) == 5;
+  std::vector<char> buf;
+  for (const auto &fld : ckpt_fields(h)) {
+    buf.resize(fld.bytes);
+    hipError_t e = hipMemcpyAsync(buf.data(), fld.dev, fld.bytes, hipMemcpyDeviceToHost, h->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+    if (e != hipSuccess) {
+      std::fclose(f);
+      return fail(RCM_ERR_HIP, std::string("rcm_checkpoint_save: ") + hipGetErrorString(e));
+    }
+    ok = ok && std::fwrite(buf.data(), 1, fld.bytes, f) == fld.bytes;
+  }
+  ok = (std::fclose(f) == 0) && ok;
+  return ok ? RCM_OK : fail(RCM_ERR_IO, std::string("rcm_checkpoint_save: write failed: ") + path);
+}
+
+int rcm_checkpoint_load(rcm_ensemble *h, const char *path) {
+  if (!h || !path) return fail(RCM_ERR_ARG, "rcm_checkpoint_load: bad argument");
+  if (h->mode == rcm::MODE_NONE || !h->have_grid)
+    return fail(RCM_ERR_STATE, "rcm_checkpoint_load: set the grid and the spectral tables first");
+  if (int rc = use_device(h)) return rc;
+  FILE *f = std::fopen(path, "rb");
+  if (!f) return fail(RCM_ERR_IO, std::string("rcm_checkpoint_load: cannot open ") + path);
+  char magic[8];
+  long long hdr[5];
+  if (std::fread(magic, 1, 8, f) != 8 || std::memcmp(magic, "RCMCKPT1", 8) != 0 ||
+      std::fread(hdr, sizeof(long long), 5, f) != 5) {
+    std::fclose(f);
+    return fail(RCM_ERR_FORMAT, std::string("rcm_checkpoint_load: not an RCMCKPT1 file: ") + path);
+  }
+  if (hdr[0] != h->ncol || hdr[1] != NL || hdr[2] != h->d.ngas || hdr[3] != h->mode || hdr[4] < 0) {
+    std::fclose(f);
+    return fail(RCM_ERR_ARG, "rcm_checkpoint_load: checkpoint does not match this ensemble (ncol/nlayer/species/mode)");
+  }
+  if (!h->d.gas)
+    if (int rc = dev_alloc(h, &h->d.gas, (size_t)h->ncol * NL * h->d.ngas)) {
+      std::fclose(f);
+      return rc;
+    }
+  std::vector<char> buf;
+  for (const auto &fld : ckpt_fields(h)) {
+    buf.resize(fld.bytes);
+    if (std::fread(buf.data(), 1, fld.bytes, f) != fld.bytes) {
+      std::fclose(f);
+      return fail(RCM_ERR_FORMAT, std::string("rcm_checkpoint_load: truncated file: ") + path);
+    }
+    hipError_t e = hipMemcpyAsync(fld.dev, buf.data(), fld.bytes, hipMemcpyHostToDevice, h->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+    if (e != hipSuccess) {
+      std::fclose(f);
+      return fail(RCM_ERR_HIP, std::string("rcm_checkpoint_load: ") + hipGetErrorString(e));
+    }
+  }
+  std::fclose(f);
+  h->step_index = hdr[4];
+  h->have_columns = true;
+  if (h->mode == rcm::MODE_REPWVL) h->d.species_mask = 0x1ff;  // unknown zero pattern: interpolate all nine
   return RCM_OK;
 }
 

@@ -8,8 +8,14 @@
 // reference's value as the default.  The loop body runs on the GPU (rcm_step); with --ncol N the
 // column is replicated into a CO2 sweep and column 0.. are integrated together.
 //
-//   rcm_main [--atm F] [--table F.rtab | --lbl-dir D] [--steps N] [--output-steps K]
-//            [--co2-factor X] [--ncol N] [--tsfc T] [--output F] [--device I] [--print-col C]
+//   rcm_main [--atm F] [--table F.rtab | --lbl-dir D [--lbl-cache F]] [--steps N] [--output-steps K]
+//            [--co2-factor X] [--ncol N] [--tsfc T] [--tau-s X] [--output F] [--device I]
+//            [--print-cols a,b,..] [--equilibrium TOL_K] [--restart F] [--checkpoint F]
+// --lbl-cache: binary cache of the five ASCII tables (read if present, else written after parsing).
+// --print-cols: columns whose profile block is written at every output time (default 0).
+// --equilibrium: instead of a fixed count, step until the adjusted profile changes by <= TOL_K per
+//                step in every column (rcm_run_to_equilibrium), at most --steps iterations.
+// --restart / --checkpoint: resume from / write the binary restart file (rcm_checkpoint_*).
 #include <chrono>
 #include <cmath>
 #include <cstdio>
@@ -25,14 +31,16 @@ namespace {
 struct Options {
   std::string atm = "./repwvl_V2.01_cpp/test.atm";                // main.cpp:397
   std::string table = "./repwvl_V2.01_cpp/Reduced100Forcing.rtab"; // main.cpp:500 (flattened .nc)
-  std::string lbl_dir;
+  std::string lbl_dir, lbl_cache, restart, checkpoint;
+  std::vector<int> print_cols = {0};
+  double equilibrium = -1;  // < 0: fixed step count
   std::string output = "output.txt";                               // main.cpp:105,512
   int steps = 1;          // Consts::n_steps, main.cpp:83
   int output_steps = 10;  // Consts::output_steps, main.cpp:84
   double co2_factor = 1;  // main.cpp:452
   double tsfc = 288.2;    // main.cpp:357
   double tau_s = 2.0;     // main.cpp:86
-  int ncol = 1, device = 0, print_col = 0;
+  int ncol = 1, device = 0;
 };
 
 [[noreturn]] void die(const std::string &what) {
@@ -67,13 +75,27 @@ Options parse(int argc, char **argv) {
     else if (a == "--tau-s") o.tau_s = std::atof(val());
     else if (a == "--ncol") o.ncol = std::atoi(val());
     else if (a == "--device") o.device = std::atoi(val());
-    else if (a == "--print-col") o.print_col = std::atoi(val());
+    else if (a == "--lbl-cache") o.lbl_cache = val();
+    else if (a == "--restart") o.restart = val();
+    else if (a == "--checkpoint") o.checkpoint = val();
+    else if (a == "--equilibrium") o.equilibrium = std::atof(val());
+    else if (a == "--print-cols" || a == "--print-col") {
+      o.print_cols.clear();
+      for (const char *p = val(); *p;) {
+        char *e = nullptr;
+        o.print_cols.push_back((int)std::strtol(p, &e, 10));
+        if (e == p) break;
+        p = (*e == ',') ? e + 1 : e;
+      }
+    }
     else {
       std::fprintf(stderr, "rcm_main: unknown option %s\n", a.c_str());
       std::exit(2);
     }
   }
-  if (o.ncol < 1 || o.steps < 0 || o.output_steps < 1 || o.print_col < 0 || o.print_col >= o.ncol) {
+  bool ok = o.ncol >= 1 && o.steps >= 0 && o.output_steps >= 1 && !o.print_cols.empty();
+  for (int c : o.print_cols) ok = ok && c >= 0 && c < o.ncol;
+  if (!ok) {
     std::fprintf(stderr, "rcm_main: bad option value\n");
     std::exit(2);
   }
@@ -163,10 +185,27 @@ int main(int argc, char **argv) {
   if (lbl) {
     std::vector<double> wvl;
     std::vector<std::vector<double>> tabs;
-    load_lbl(o.lbl_dir, nlayer, wvl, tabs);
     const double *tp[RCM_NSPEC_LBL];
-    for (int s = 0; s < RCM_NSPEC_LBL; ++s) tp[s] = tabs[s].data();
-    CK(rcm_set_lbl_tables(h, (int)wvl.size(), wvl.data(), tp, h2o_ref.data()));
+    int n_nodes = 0, nl_file = 0;
+    double *cw = nullptr, *ct = nullptr;
+    FILE *probe = o.lbl_cache.empty() ? nullptr : std::fopen(o.lbl_cache.c_str(), "rb");
+    if (probe) {  // parse the ASCII spectra once, then reuse the binary cache
+      std::fclose(probe);
+      CK(rcm_lbl_cache_read(o.lbl_cache.c_str(), &n_nodes, &nl_file, &cw, &ct));
+      if (nl_file != nlayer) {
+        std::fprintf(stderr, "rcm_main: %s has %d layers, need %d\n", o.lbl_cache.c_str(), nl_file, nlayer);
+        return 1;
+      }
+      for (int s = 0; s < RCM_NSPEC_LBL; ++s) tp[s] = ct + (size_t)s * n_nodes * nlayer;
+      CK(rcm_set_lbl_tables(h, n_nodes, cw, tp, h2o_ref.data()));
+      rcm_free(cw);
+      rcm_free(ct);
+    } else {
+      load_lbl(o.lbl_dir, nlayer, wvl, tabs);
+      for (int s = 0; s < RCM_NSPEC_LBL; ++s) tp[s] = tabs[s].data();
+      if (!o.lbl_cache.empty()) CK(rcm_lbl_cache_write(o.lbl_cache.c_str(), (int)wvl.size(), nlayer, wvl.data(), tp));
+      CK(rcm_set_lbl_tables(h, (int)wvl.size(), wvl.data(), tp, h2o_ref.data()));
+    }
   } else {
     long long dims[4];
     double *blob = nullptr;
@@ -184,6 +223,7 @@ int main(int argc, char **argv) {
   CK(rcm_solar_setup(o.tau_s, mu_s, 20, 0.85, 0.12, (double)0.5f, 1361.0, solar));
   CK(rcm_set_forcing(h, solar[6], 17, o.tau_s / 2.0));  // main.cpp:92, 267
   CK(rcm_set_columns(h, T0.data(), Ts0.data(), gas.data(), relhum.data()));
+  if (!o.restart.empty()) CK(rcm_checkpoint_load(h, o.restart.c_str()));
   FILE *out = std::fopen(o.output.c_str(), "a");  // main.cpp:512 (append)
   if (!out) {
     std::fprintf(stderr, "rcm_main: cannot open %s\n", o.output.c_str());
@@ -195,28 +235,46 @@ int main(int argc, char **argv) {
   std::vector<double> Tadj(nlayer), theta(nlayer);
   float time_h = 0.f;
   const auto t0 = std::chrono::steady_clock::now();
-  int i = 0;
-  while (i <= o.steps) {
-    if (i % o.output_steps == 0) {  // main.cpp:543-546, before this iteration's radiative transfer
-      CK(rcm_get_profile(h, o.print_col, Tadj.data(), theta.data(), &time_h));
+  auto write_blocks = [&]() {  // main.cpp:543-546 for every selected column
+    for (int c : o.print_cols) {
+      CK(rcm_get_profile(h, c, Tadj.data(), theta.data(), &time_h));
       CK(rcm_write_profile(out, nlayer, player.data(), Tadj.data(), theta.data(), time_h));
     }
+  };
+  int i = 0;
+  double resid = -1;
+  while (i <= o.steps) {
+    if (i % o.output_steps == 0) write_blocks();  // before this iteration's radiative transfer
     const int next_out = (i / o.output_steps + 1) * o.output_steps;
     const int run = std::min(next_out, o.steps + 1) - i;  // iterations until the next output or the end
-    CK(rcm_step(h, run));
-    i += run;
+    if (o.equilibrium >= 0) {
+      int done = 0;
+      CK(rcm_run_to_equilibrium(h, o.equilibrium, run, run, &done, &resid));
+      i += done;
+      if (resid <= o.equilibrium) {
+        write_blocks();  // the equilibrium profile
+        break;
+      }
+    } else {
+      CK(rcm_step(h, run));
+      i += run;
+    }
   }
+  const int iterations = std::min(i, o.steps + 1);
   CK(rcm_sync(h));
   const double secs = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
   std::fclose(out);
 
+  if (!o.checkpoint.empty()) CK(rcm_checkpoint_save(h, o.checkpoint.c_str()));
   std::vector<double> Tsfc(o.ncol);
   std::vector<float> tm(o.ncol);
   CK(rcm_get_state(h, nullptr, Tsfc.data(), tm.data(), nullptr));
   std::fprintf(stderr, "rcm_main: %d column(s) x %d iterations (%d spectral points) in %.3f s = %.1f column-timesteps/s\n",
-               o.ncol, o.steps + 1, rcm_nspectral(h), secs, o.ncol * (double)(o.steps + 1) / secs);
-  std::fprintf(stderr, "rcm_main: column %d: T_surface %.10f K, time %.6f h\n", o.print_col, Tsfc[o.print_col],
-               tm[o.print_col]);
+               o.ncol, iterations, rcm_nspectral(h), secs, o.ncol * (double)iterations / secs);
+  if (o.equilibrium >= 0)
+    std::fprintf(stderr, "rcm_main: equilibrium residual %.3e K/step (tolerance %.3e)\n", resid, o.equilibrium);
+  for (int c : o.print_cols)
+    std::fprintf(stderr, "rcm_main: column %d: T_surface %.10f K, time %.6f h\n", c, Tsfc[c], tm[c]);
   CK(rcm_destroy(h));
   return 0;
 }

@@ -54,6 +54,8 @@ def load():
     lib.orc_destroy.argtypes = [C.c_void_p]
     lib.orc_set_grid.argtypes = [C.c_void_p, _dp]
     lib.orc_set_forcing.argtypes = [C.c_void_p, C.c_double, C.c_int, C.c_double]
+    lib.orc_set_column_forcing.argtypes = [C.c_void_p, _dp, C.POINTER(C.c_int), _dp]
+    lib.orc_get_residual.argtypes = [C.c_void_p, _dp]
     lib.orc_set_repwvl_tables.argtypes = [C.c_void_p] + [C.c_int] * 4 + [_dp] * 6
     lib.orc_set_lbl_tables.argtypes = [C.c_void_p, C.c_int, _dp, C.POINTER(_dp), _dp]
     lib.orc_set_columns.argtypes = [C.c_void_p] + [_dp] * 4
@@ -146,6 +148,30 @@ class OracleEnsemble:
 
     def set_forcing(self, solar_irr, cloud_layer=17, cloud_tau=1.0):
         self._ck(self.lib.orc_set_forcing(self.h, solar_irr, cloud_layer, cloud_tau))
+
+    def set_column_forcing(self, solar_irr=None, cloud_layer=None, cloud_tau=None):
+        a = None if solar_irr is None else np.ascontiguousarray(solar_irr, dtype=np.float64)
+        b = None if cloud_layer is None else np.ascontiguousarray(cloud_layer, dtype=np.int32)
+        c = None if cloud_tau is None else np.ascontiguousarray(cloud_tau, dtype=np.float64)
+        self._ck(self.lib.orc_set_column_forcing(self.h, _p(a), None if b is None else b.ctypes.data_as(
+            C.POINTER(C.c_int)), _p(c)))
+
+    def get_residual(self):
+        r = np.zeros(self.ncol)
+        self._ck(self.lib.orc_get_residual(self.h, _p(r)))
+        return r
+
+    def run_to_equilibrium(self, tol_K, max_steps, check_every=10):
+        # same control flow as rcm_run_to_equilibrium
+        done, worst = 0, float("inf")
+        while done < max_steps:
+            n = min(check_every, max_steps - done)
+            self.step(n)
+            done += n
+            worst = float(self.get_residual().max())
+            if worst <= tol_K:
+                break
+        return done, worst
 
     def set_repwvl_tables(self, t):
         arrs = [np.ascontiguousarray(t[k], dtype=np.float64)

@@ -318,3 +318,137 @@ def test_config1_single_column_full_lbl_spectrum_against_oracle(pkg, olib, big):
     g.step(2), o.step(2)
     _check_fluxes(g, o, 1e-9)
     _check_state(g, o)
+
+
+# ---- widened rows and the equilibrium run -------------------------------
+def test_per_column_forcing_against_oracle(pkg, olib):
+    inp = H.make_inputs(pkg, "repwvl", 6, table="Reduced20")
+    solar = np.array([236.88, 180.0, 260.5, 0.0, 300.0, 236.88])
+    layer = np.array([17, -1, 3, 19, 0, 9], dtype=np.int32)  # incl. none, top, bottom, both lane halves
+    ctau = np.array([1.0, 5.0, 0.25, 2.0, 0.7, 3.0])
+    for mode in ("repwvl", "lbl"):
+        if mode == "lbl":
+            inp = H.make_inputs(pkg, "lbl", 6, n_nodes=500, atm="fpda.lbl.atm")
+        g, o = H.gpu_ensemble(pkg, inp), H.oracle_ensemble(olib, inp)
+        g.set_column_forcing(solar, layer, ctau), o.set_column_forcing(solar, layer, ctau)
+        for c in range(6):
+            np.testing.assert_allclose(g.get_tau(c), o.get_tau(c), rtol=1e-12, atol=0)
+        g.step(4), o.step(4)
+        _check_fluxes(g, o)
+        _check_state(g, o)
+        g.set_column_forcing(cloud_tau=ctau * 2), o.set_column_forcing(cloud_tau=ctau * 2)  # NULL keeps the others
+        g.step(1), o.step(1)
+        _check_fluxes(g, o)
+
+
+def test_solar_setup_on_device(pkg, olib, probe):
+    import oracle_lib as ol
+    n = 64
+    rng = np.random.default_rng(5)
+    tau_s = np.concatenate([[2.0, 2.07672, 2.05], rng.uniform(0.1, 8.0, n - 3)])
+    mu_s = np.concatenate([[np.cos(60 * np.pi / 180.0), 0.5, 0.5], rng.uniform(0.05, 1.0, n - 3)])
+    alb = np.concatenate([[0.12, 0.12, 0.12], rng.uniform(0.0, 0.9, n - 3)])
+    inp = H.make_inputs(pkg, "repwvl", n, table="Reduced10")
+    g = H.gpu_ensemble(pkg, inp)
+    out = g.solar_setup_columns(tau_s, mu_s, alb)
+    want = np.zeros((n, 7))
+    for c in range(n):
+        olib.orc_solar_setup(tau_s[c], mu_s[c], 20, 0.85, alb[c], 0.5, 1361.0, ol._p(want[c]))
+    np.testing.assert_allclose(out, want, rtol=2e-14, atol=0)
+    ref = probe["solar_tau_s_2.0"]  # the reference's own numbers
+    for k, name in enumerate(("r_dir", "s_dir", "t_dir", "r", "t", "r_total", "solar_irr")):
+        assert abs(out[0, k] / ref[name] - 1) <= 2e-14
+    for c, b in ((1, probe["output_txt_banners"][0]), (2, probe["output_txt_banners"][1])):  # output.txt:3-6, 30-33
+        assert f"{out[c, 5]:f}" == f"{b['albedo']:f}" and f"{out[c, 6]:f}" == f"{b['solar']:f}"
+    # the kernel installed solar_irr and cloud_tau = tau_s/2 (main.cpp:267) per column.  Step only with
+    # moderate forcing: a weakly heated column makes every dE negative, and the reference's SIGNED
+    # max(dE) (main.cpp:157) then yields a negative time step and a blow-up -- on both sides.
+    tau_s, mu_s, alb = rng.uniform(1.0, 3.0, n), rng.uniform(0.4, 0.7, n), rng.uniform(0.05, 0.3, n)
+    out = g.solar_setup_columns(tau_s, mu_s, alb)
+    o = H.oracle_ensemble(olib, inp)
+    o.set_column_forcing(out[:, 6], None, tau_s / 2.0)
+    g.step(3), o.step(3)
+    assert np.all(np.isfinite(o.get_fluxes()["dE"]))
+    _check_fluxes(g, o)
+    _check_state(g, o)
+
+
+def test_checkpoint_resume_is_bit_identical(pkg, tmp_path):
+    for mode, kw in (("repwvl", dict(table="Reduced20")), ("lbl", dict(n_nodes=400, atm="fpda.lbl.atm"))):
+        inp = H.make_inputs(pkg, mode, 5, **kw)
+        a = H.gpu_ensemble(pkg, inp)
+        a.set_column_forcing(cloud_tau=np.linspace(0.5, 1.5, 5))
+        a.step(7)
+        path = str(tmp_path / f"{mode}.ckpt")
+        a.checkpoint_save(path)
+        a.step(6)
+        b = pkg.Ensemble(5)
+        b.set_grid(inp["cols"]["plevel"])
+        if mode == "repwvl":
+            b.set_repwvl_tables(inp["table"])
+        else:
+            b.set_lbl_tables(inp["wvl"], inp["tabs"], inp["cols"]["h2o_ref"])
+        b.checkpoint_load(path)
+        b.step(6)
+        sa, sb = a.get_state(), b.get_state()
+        for k in sa:
+            np.testing.assert_array_equal(sa[k], sb[k], err_msg=k)
+        fa, fb = a.get_fluxes(), b.get_fluxes()
+        for k in fa:
+            np.testing.assert_array_equal(fa[k], fb[k], err_msg=k)
+        np.testing.assert_array_equal(a.get_gas(), b.get_gas())
+    with pytest.raises(pkg.RcmError) as e:
+        pkg.Ensemble(4).checkpoint_load(path)  # nothing set yet
+    assert e.value.code == -2
+
+
+def test_run_to_equilibrium_matches_oracle(pkg, olib):
+    inp = H.make_inputs(pkg, "repwvl", 3, table="Reduced10")
+    g, o = H.gpu_ensemble(pkg, inp), H.oracle_ensemble(olib, inp)
+    assert np.all(g.get_residual() == 0.0)
+    g.step(1), o.step(1)
+    assert np.all(g.get_residual() == 1e300) and np.all(o.get_residual() == 1e300)
+    n_g, r_g = g.run_to_equilibrium(0.12, 400, 25)
+    n_o, r_o = o.run_to_equilibrium(0.12, 400, 25)
+    assert n_g == n_o and 25 <= n_g < 400
+    assert abs(r_g - r_o) <= 1e-9 and r_g <= 0.12
+    np.testing.assert_allclose(g.get_residual(), o.get_residual(), rtol=0, atol=1e-9)
+    _check_state(g, o)
+    n2, r2 = g.run_to_equilibrium(0.0, 30, 7)  # unreachable tolerance: stops at max_steps
+    assert n2 == 30 and r2 > 0
+
+
+def test_driver_restart_cache_equilibrium_and_column_selection(pkg, olib, golden, tmp_path):
+    base = ["--atm", os.path.join(golden, "test.atm"), "--table", os.path.join(golden, "Reduced10Forcing.rtab")]
+    # (i) 20 iterations in one go == 10 + checkpoint, then restart + 10
+    _run_driver(base + ["--steps", "19", "--output-steps", "100", "--output", "a.txt", "--checkpoint", "a.ck"], tmp_path)
+    _run_driver(base + ["--steps", "9", "--output-steps", "100", "--output", "b.txt", "--checkpoint", "b.ck"], tmp_path)
+    _run_driver(base + ["--steps", "9", "--output-steps", "100", "--output", "c.txt", "--restart", "b.ck",
+                        "--checkpoint", "c.ck"], tmp_path)
+    assert (tmp_path / "a.ck").read_bytes() == (tmp_path / "c.ck").read_bytes()
+    # (ii) ensemble with selected columns: blocks for columns 0 and 2 at each output time
+    _run_driver(base + ["--ncol", "3", "--steps", "10", "--output-steps", "10", "--print-cols", "0,2", "--output",
+                        "e.txt"], tmp_path)
+    rows = (tmp_path / "e.txt").read_text().splitlines()
+    assert len(rows) == 7 + 2 * 2 * 20
+    assert rows[7:27] == rows[27:47]  # t = 0: both columns still hold the same profile
+    assert rows[47:67] != rows[67:87]  # 10 steps later the CO2 sweep has separated them
+    # (iii) equilibrium run stops early and reports the residual
+    r = _run_driver(base + ["--steps", "400", "--output-steps", "50", "--equilibrium", "0.12", "--output", "q.txt"],
+                    tmp_path)
+    assert "equilibrium residual" in r.stderr
+    o = H.oracle_ensemble(olib, H.make_inputs(pkg, "repwvl", 1, table="Reduced10", perturb=False))
+    n_o, _ = o.run_to_equilibrium(0.12, 400, 50)
+    assert f"x {n_o} iterations" in r.stderr
+    # (iv) lbl ASCII directory -> binary cache -> same run from the cache
+    inp = H.make_inputs(pkg, "lbl", 1, n_nodes=120, atm="fpda.lbl.atm", perturb=False)
+    for s, name in enumerate(("co2", "h2o", "o3", "ch4", "n2o")):
+        np.savetxt(tmp_path / f"lbl.{name}.asc", np.concatenate([inp["wvl"][:, None], inp["tabs"][s]], axis=1), fmt="%.17g")
+    lbl = ["--atm", os.path.join(golden, "fpda.lbl.atm"), "--lbl-dir", str(tmp_path), "--lbl-cache", "lbl.bin",
+           "--steps", "3", "--output-steps", "3"]
+    _run_driver(lbl + ["--output", "l1.txt"], tmp_path)
+    assert (tmp_path / "lbl.bin").exists()
+    for name in ("co2", "h2o", "o3", "ch4", "n2o"):
+        os.remove(tmp_path / f"lbl.{name}.asc")  # second run must come from the cache alone
+    _run_driver(lbl + ["--output", "l2.txt"], tmp_path)
+    assert (tmp_path / "l1.txt").read_text() == (tmp_path / "l2.txt").read_text()

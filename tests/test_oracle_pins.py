@@ -246,3 +246,22 @@ def test_output_writers_reproduce_reference_formats(rcm, golden, tmp_path):
     # the recorded run printed tau_s with %2.5f (older revision); the current source prints %2.3f (main.cpp:516)
     assert got[2] == ref[2].replace("2.07672", "2.077")
     assert got[0:2] == ref[0:2] and got[3:27] == ref[3:27]
+
+
+def test_lbl_binary_cache_round_trip(rcm, tmp_path):
+    wvl, tabs = rcm.synth_lbl_tables(257)
+    p = str(tmp_path / "lbl.cache")
+    rcm.lbl_cache_write(p, wvl, tabs)
+    assert os.path.getsize(p) == 8 + 16 + 8 * 257 * (1 + 5 * 20)
+    w2, t2 = rcm.lbl_cache_read(p)
+    np.testing.assert_array_equal(w2, wvl)
+    for a, b in zip(tabs, t2):
+        np.testing.assert_array_equal(a, b)
+    # on disk: [species][layer][node], node fastest
+    raw = np.fromfile(p, dtype="<f8", offset=24)
+    np.testing.assert_array_equal(raw[257:257 + 257], tabs[0][:, 0])
+    with open(p, "r+b") as f:
+        f.truncate(1000)
+    with pytest.raises(rcm.RcmError) as e:
+        rcm.lbl_cache_read(p)
+    assert e.value.code == -6
