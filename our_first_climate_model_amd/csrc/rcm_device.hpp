@@ -177,6 +177,12 @@ __device__ inline double cplkavg_dev(double wnumlo, double wnumhi, double t, dou
   return ans * tpre;                                              // :237
 }
 
+// Out-of-line copy for callers that unroll the fast path: the wide-band branch is rare on
+// line-by-line grids and its code is large.
+__device__ __attribute__((noinline)) double cplkavg_slow(double wnumlo, double wnumhi, double t, double tpre) {
+  return cplkavg_dev(wnumlo, wnumhi, t, tpre);
+}
+
 // Narrow-band fast path of cplkavg.  When the band is so narrow that hh = v1 - v0 < kHhFast, the
 // reference's Simpson iteration (cplkavg.cpp:159-181) converges at n = 2 with a truncation error
 // of hh^4/2880 * (f4/f) <= 6e-15 (f4 = fourth derivative), i.e. it returns the exact integral to

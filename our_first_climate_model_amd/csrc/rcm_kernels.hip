@@ -38,6 +38,9 @@ constexpr int WPB = 4;       // waves per block = columns per block (one per SIM
 #ifndef RCM_PAIR_LB
 #define RCM_PAIR_LB 2  // waves per SIMD the lane-pair lbl kernel is register-allocated for
 #endif
+#ifndef RCM_PAIR_PLK_UNROLL
+#define RCM_PAIR_PLK_UNROLL 1  // band-Planck evaluations unrolled together in the lane-pair kernels
+#endif
 #ifndef RCM_PLK_UNROLL
 #define RCM_PLK_UNROLL 1  // independent band-Planck evaluations in flight
 #endif
@@ -241,9 +244,8 @@ __device__ __forceinline__ double repwvl_tau_layer(const Dev &d, const RepwvlLds
 // ---------------------------------------------------------------------------------------------
 // Thermal RT, lbl spectra: radiative_transfer (main.cpp:320-344) with the band Planck source
 // cplkavg (cplkavg.cpp:124-243) and optical depths assembled on the fly.
-// grid = nchunk * ceil(ncol/4) blocks of 4 waves; the 4 waves of a block (and neighbouring
-// blocks) work on the SAME spectral chunk of different columns, so a table tile is fetched
-// from HBM once and then served from L2 to every column.
+// grid = ceil(nchunk * ncol / 4) blocks of 4 waves; consecutive waves work on the SAME spectral chunk
+// of different columns, so a table tile is fetched from HBM once and then served from L2.
 // ---------------------------------------------------------------------------------------------
 template <int EXPV, int CUBE, int PLK>
 __global__ __launch_bounds__(64 * WPB, RCM_LB) void k_rt_lbl(Dev d) {
@@ -251,11 +253,14 @@ __global__ __launch_bounds__(64 * WPB, RCM_LB) void k_rt_lbl(Dev d) {
   __shared__ double s_stage[WPB][NLEV][64];  // per-lane scratch column, indexable at run time
   const int lane = threadIdx.x & 63;
   const int wib = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int ncg = (d.ncol + WPB - 1) / WPB;
-  const int chunk = blockIdx.x / ncg;
-  const int colraw = (blockIdx.x - chunk * ncg) * WPB + wib;
-  const bool valid = colraw < d.ncol;
-  const int col = valid ? colraw : d.ncol - 1;
+  // work item = (chunk, column), column fastest: the waves of a block and neighbouring blocks share
+  // the chunk (its table tile stays in L2); a small ensemble still fills every wave slot
+  const long nitem = (long)d.ncol * d.nchunk;
+  const long item_raw = (long)blockIdx.x * WPB + wib;
+  const bool valid = item_raw < nitem;
+  const long item = valid ? item_raw : nitem - 1;
+  const int chunk = (int)(item / d.ncol);
+  const int col = (int)(item - (long)chunk * d.ncol);
   double(*st)[64] = s_stage[wib];
   // LDS: [0..19] Tlayer, [20] T_surface, [21..41] sigdpi*T^4, [48..147] gas multipliers [5][20],
   //      [150..170] sigdpi*T^4*conc, [171..191] 1/T
@@ -398,11 +403,14 @@ __global__ __launch_bounds__(64 * WPB, RCM_PAIR_LB) void k_rt_lbl_pair(Dev d) {
   __shared__ double s_stage[WPB][NH + 1][64];
   const int lane = threadIdx.x & 63;
   const int wib = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int ncg = (d.ncol + WPB - 1) / WPB;
-  const int chunk = blockIdx.x / ncg;
-  const int colraw = (blockIdx.x - chunk * ncg) * WPB + wib;
-  const bool valid = colraw < d.ncol;
-  const int col = valid ? colraw : d.ncol - 1;
+  // work item = (chunk, column), column fastest: the waves of a block and neighbouring blocks share
+  // the chunk (its table tile stays in L2); a small ensemble still fills every wave slot
+  const long nitem = (long)d.ncol * d.nchunk;
+  const long item_raw = (long)blockIdx.x * WPB + wib;
+  const bool valid = item_raw < nitem;
+  const long item = valid ? item_raw : nitem - 1;
+  const int chunk = (int)(item / d.ncol);
+  const int col = (int)(item - (long)chunk * d.ncol);
   const int p = lane & 1;
   PairLds &s = s_col[wib];
   double(*st)[64] = s_stage[wib];
@@ -465,11 +473,11 @@ __global__ __launch_bounds__(64 * WPB, RCM_PAIR_LB) void k_rt_lbl_pair(Dev d) {
     const double wnumlo = 1.0E7 / d.lbl_wvl[b + 1];  // cplkavg.cpp:142
     const double c2lo = 1.438786 * wnumlo, c2hi = 1.438786 * wnumhi;  // cplkavg.cpp:152-153
     const bool narrow = (wnumhi - wnumlo) / wnumhi < 1.e-2;           // cplkavg.cpp:155
-#pragma unroll 1
+#pragma unroll RCM_PAIR_PLK_UNROLL
     for (int k = 0; k <= NH; ++k) {
       double Bk;
       if (!(narrow && cplkavg_fast(c2lo, c2hi, s.T[p][k], s.rT[p][k], s.pc[p][k], &Bk)))
-        Bk = cplkavg_dev(wnumlo, wnumhi, s.T[p][k], s.tp[p][k]);
+        Bk = cplkavg_slow(wnumlo, wnumhi, s.T[p][k], s.tp[p][k]);
       st[k][lane] = Bk;
     }
     double B[NH];
@@ -510,11 +518,14 @@ __global__ __launch_bounds__(64 * WPB, RCM_PAIR_LB) void k_rt_repwvl_pair(Dev d)
   __shared__ double s_stage[WPB][NH + 1][64];
   const int lane = threadIdx.x & 63;
   const int wib = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int ncg = (d.ncol + WPB - 1) / WPB;
-  const int chunk = blockIdx.x / ncg;
-  const int colraw = (blockIdx.x - chunk * ncg) * WPB + wib;
-  const bool valid = colraw < d.ncol;
-  const int col = valid ? colraw : d.ncol - 1;
+  // work item = (chunk, column), column fastest: the waves of a block and neighbouring blocks share
+  // the chunk (its table tile stays in L2); a small ensemble still fills every wave slot
+  const long nitem = (long)d.ncol * d.nchunk;
+  const long item_raw = (long)blockIdx.x * WPB + wib;
+  const bool valid = item_raw < nitem;
+  const long item = valid ? item_raw : nitem - 1;
+  const int chunk = (int)(item / d.ncol);
+  const int col = (int)(item - (long)chunk * d.ncol);
   const int p = lane & 1;
   RepwvlPairLds &s = s_col[wib];
   double(*st)[64] = s_stage[wib];
@@ -620,11 +631,14 @@ __global__ __launch_bounds__(64 * WPB, 2) void k_rt_repwvl(Dev d) {
   __shared__ double s_stage[WPB][NLEV][64];
   const int lane = threadIdx.x & 63;
   const int wib = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int ncg = (d.ncol + WPB - 1) / WPB;
-  const int chunk = blockIdx.x / ncg;
-  const int colraw = (blockIdx.x - chunk * ncg) * WPB + wib;
-  const bool valid = colraw < d.ncol;
-  const int col = valid ? colraw : d.ncol - 1;
+  // work item = (chunk, column), column fastest: the waves of a block and neighbouring blocks share
+  // the chunk (its table tile stays in L2); a small ensemble still fills every wave slot
+  const long nitem = (long)d.ncol * d.nchunk;
+  const long item_raw = (long)blockIdx.x * WPB + wib;
+  const bool valid = item_raw < nitem;
+  const long item = valid ? item_raw : nitem - 1;
+  const int chunk = (int)(item / d.ncol);
+  const int col = (int)(item - (long)chunk * d.ncol);
   RepwvlLds &s = s_col[wib];
   double(*st)[64] = s_stage[wib];
   repwvl_prologue(d, col, lane, s);
@@ -705,17 +719,25 @@ __global__ void k_pre(Dev d, int first) {
   }
 }
 
-// One wave per column.  Sums the chunk partials in chunk order, then the tail of
-// radiative_transfer (main.cpp:337-341), calculate_timestep (:156-162), thermodynamics
-// (:164-176) and the time accumulation (:581).
-__global__ __launch_bounds__(64) void k_post(Dev d) {
+// One block of P waves per column (P = blockDim.x/64 <= 16).  Wave q sums the chunk partials
+// q, q+P, q+2P, .. in that order, the P sums are combined in wave order (deterministic for a given
+// chunking), then lane 0 runs the tail of radiative_transfer (main.cpp:337-341), calculate_timestep
+// (:156-162), thermodynamics (:164-176) and the time accumulation (:581).
+__global__ __launch_bounds__(1024) void k_post(Dev d) {
+  __shared__ double s_part[16][PSTRIDE];
   __shared__ double s_E[PSTRIDE];
   const int c = blockIdx.x;
-  const int j = threadIdx.x;
+  const int j = threadIdx.x & 63, q = threadIdx.x >> 6, P = blockDim.x >> 6;
   if (j < PSTRIDE) {
     const double *p = d.partial + (size_t)c * d.nchunk * PSTRIDE + j;
     double acc = 0.0;
-    for (int k = 0; k < d.nchunk; ++k) acc += p[(size_t)k * PSTRIDE];
+    for (int k = q; k < d.nchunk; k += P) acc += p[(size_t)k * PSTRIDE];
+    s_part[q][j] = acc;
+  }
+  __syncthreads();
+  if (q == 0 && j < PSTRIDE) {
+    double acc = s_part[0][j];
+    for (int r = 1; r < P; ++r) acc += s_part[r][j];
     s_E[j] = acc;
     if (j < NLEV)
       d.E_down[(size_t)c * NLEV + j] = acc;
@@ -723,7 +745,7 @@ __global__ __launch_bounds__(64) void k_post(Dev d) {
       d.E_up[(size_t)c * NLEV + (j - NLEV)] = acc;
   }
   __syncthreads();
-  if (j != 0) return;
+  if (threadIdx.x != 0) return;
   const double *Ed = s_E, *Eu = s_E + NLEV;
   double dE[NL];
 #pragma unroll
@@ -938,21 +960,32 @@ int derive_repwvl_layers(rcm_ensemble *h) {
   return RCM_OK;
 }
 
-// Spectral chunking: ~16 rounds of the 2048 waves the chip holds at 2 waves/SIMD (a short tail and
-// room for the dispatcher), but never more chunks than 32-point rows.  Pure function of
-// (ncol, nspec, user override).
+// Spectral chunking.  Pure function of (ncol, nspec, user override); measured on the MI355X
+// (tools/time_single.py, tools/chunk_sweep.sh):
+//  * a wave needs ~8 passes of 32 points to amortise its column prologue (64 columns: 512 chunks beat
+//    4096 by 7 %), so big ensembles use chunks of >= 8 passes, as many as give ~2.6e5 waves in flight
+//    (10 000 columns: 27-32 chunks beat 4 by 4 %: shorter tail, better balance);
+//  * a small ensemble must first fill the chip (3072 resident waves, a lone wave reaches ~1/6 of the
+//    VALU issue rate): down to 2 passes per wave until there are ~4 rounds of waves.
 void choose_chunks(int ncol, int nspec, int user_chunks, int *nchunk_out, int *chunk_len_out) {
   const int rows = (nspec + 31) / 32;  // a lane-pair wave covers 32 spectral points per pass
-  int nchunk;
+  long nchunk;
   if (user_chunks > 0) {
     nchunk = user_chunks;
   } else {
-    const long target_waves = 256L * 8 * 16;
-    nchunk = (int)((target_waves + ncol - 1) / ncol);
+    const long fill = (12288L + ncol - 1) / ncol;          // chunks that give 4 rounds of resident waves
+    const long amortised = rows / 8 > 0 ? rows / 8 : 1;    // chunks of 8 passes
+    if (fill >= amortised) {
+      nchunk = fill;
+      if (nchunk > rows / 2) nchunk = rows / 2;            // keep two passes per wave
+    } else {
+      nchunk = (262144L + ncol - 1) / ncol;
+      if (nchunk > amortised) nchunk = amortised;
+    }
   }
   if (nchunk > rows) nchunk = rows;
   if (nchunk < 1) nchunk = 1;
-  const int rows_per_chunk = (rows + nchunk - 1) / nchunk;
+  const int rows_per_chunk = (int)((rows + nchunk - 1) / nchunk);
   *chunk_len_out = rows_per_chunk * 32;
   *nchunk_out = (rows + rows_per_chunk - 1) / rows_per_chunk;
 }
@@ -991,8 +1024,7 @@ int launch_step(rcm_ensemble *h) {
   Dev &d = h->d;
   const int first = (h->step_index == 0) ? 1 : 0;
   hipLaunchKernelGGL(rcm::k_pre, dim3((h->ncol + 127) / 128), dim3(128), 0, h->stream, d, first);
-  const int ncg = (h->ncol + rcm::WPB - 1) / rcm::WPB;
-  const int blocks = ncg * d.nchunk;
+  const int blocks = (int)(((long)h->ncol * d.nchunk + rcm::WPB - 1) / rcm::WPB);
   hipEvent_t e0 = nullptr, e1 = nullptr;
   if (h->timing) {
     if (h->events_used == h->events.size()) {
@@ -1022,7 +1054,9 @@ int launch_step(rcm_ensemble *h) {
     launch_rt<1, 1>(h, blocks);
 #endif
   if (h->timing) HIPCK(hipEventRecord(e1, h->stream));
-  hipLaunchKernelGGL(rcm::k_post, dim3(h->ncol), dim3(64), 0, h->stream, d);
+  int post_waves = d.nchunk / 16;  // waves per column in k_post: one per 16 chunk partials, 1..16
+  post_waves = post_waves < 1 ? 1 : (post_waves > 16 ? 16 : post_waves);
+  hipLaunchKernelGGL(rcm::k_post, dim3(h->ncol), dim3(64 * post_waves), 0, h->stream, d);
   HIPCK(hipGetLastError());
   ++h->step_index;
   return RCM_OK;
