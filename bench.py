@@ -175,8 +175,8 @@ def main():
             "unit": "column-timesteps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": args.scaling,
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": "10k-column ensemble x full lbl.arts 5-species spectrum "
-                                   "(BASELINE.json configs[3]); spectra synthetic, seeded",
+            "config": {"workload": f"{ncol_total}-column ensemble x full lbl.arts 5-species spectrum "
+                                   "(BASELINE.json configs[3] at the default 10000); spectra synthetic, seeded",
                        "columns_total": ncol_total, "columns_per_gpu": ncol_local, "lbl_nodes": args.nodes,
                        "bands": nband, "layers": 20, "angles": 30, "atmosphere": "fpda.lbl.atm",
                        "perturbations": "CO2 x linspace(0.5,4), RH x (1+0.1u), T_surface 288.2+2u",
