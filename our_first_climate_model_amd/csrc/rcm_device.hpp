@@ -200,13 +200,25 @@ __device__ __forceinline__ double div_by_t(double c, double t, double rT) {
   return fma(fma(-q, t, c), rT, q);
 }
 
-__device__ __forceinline__ bool cplkavg_fast(double c2lo, double c2hi, double t, double rT,
-                                             double pc, double *out) {
-  const double v0 = div_by_t(c2lo, t, rT), v1 = div_by_t(c2hi, t, rT);
+// exp(x) for the Planck argument, 0 < x < 700: same construction as exp_trans (base-2 reduction in
+// one FMA, degree-10 polynomial 5.8e-16, v_ldexp_f64), no clamps needed in that range.
+__device__ __forceinline__ double exp_pos(double x) {
+  constexpr double kLog2e = 0x1.71547652b82fep+0;
+  constexpr double kMagic = 0x1.8p+52;
+  const double z = fma(x, kLog2e, kMagic);
+  const double kf = z - kMagic;
+  const double f = fma(x, kLog2e, -kf);
+  double q = kExp2Poly10[10];
+#pragma unroll
+  for (int i = 9; i >= 0; --i) q = fma(q, f, kExp2Poly10[i]);
+  return __builtin_amdgcn_ldexp(q, __double2loint(z));
+}
+
+// The fast formula itself, preconditions established by the caller.
+__device__ __forceinline__ double cplkavg_fast_eval(double v0, double v1, double pc) {
   const double hh = v1 - v0;
-  if (!(hh < kHhFast && v0 > 2.2204460492503131e-16 && v1 < 700.0 && t >= 1.e-4)) return false;
   const double xm = 0.5 * (v0 + v1);
-  const double d = exp_poly10(xm) - 1.0;
+  const double d = exp_pos(xm) - 1.0;
   double g = __builtin_amdgcn_rcp(d);  // ~2^-26 relative; two Newton steps reach full precision
   g = fma(fma(-d, g, 1.0), g, g);
   g = fma(fma(-d, g, 1.0), g, g);
@@ -215,7 +227,15 @@ __device__ __forceinline__ bool cplkavg_fast(double c2lo, double c2hi, double t,
   const double x2 = xm * xm, x3 = x2 * xm;
   const double f = x3 * g;
   const double f2 = fma(x3, g2, fma(6.0 * x2, g1, 6.0 * xm * g));
-  *out = pc * (hh * fma(hh * hh * (1.0 / 24.0), f2, f));
+  return pc * (hh * fma(hh * hh * (1.0 / 24.0), f2, f));
+}
+
+__device__ __forceinline__ bool cplkavg_fast(double c2lo, double c2hi, double t, double rT,
+                                             double pc, double *out) {
+  const double v0 = div_by_t(c2lo, t, rT), v1 = div_by_t(c2hi, t, rT);
+  const double hh = v1 - v0;
+  if (!(hh < kHhFast && v0 > 2.2204460492503131e-16 && v1 < 700.0 && t >= 1.e-4)) return false;
+  *out = cplkavg_fast_eval(v0, v1, pc);
   return true;
 }
 

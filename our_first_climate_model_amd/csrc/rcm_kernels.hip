@@ -39,7 +39,7 @@ constexpr int WPB = 4;       // waves per block = columns per block (one per SIM
 #define RCM_PAIR_LB 2  // waves per SIMD the lane-pair lbl kernel is register-allocated for
 #endif
 #ifndef RCM_PAIR_PLK_UNROLL
-#define RCM_PAIR_PLK_UNROLL 1  // band-Planck evaluations unrolled together in the lane-pair kernels
+#define RCM_PAIR_PLK_UNROLL 3  // band-Planck evaluations in flight in the branch-free loop of the lane-pair lbl kernel
 #endif
 #ifndef RCM_PLK_UNROLL
 #define RCM_PLK_UNROLL 1  // independent band-Planck evaluations in flight
@@ -434,6 +434,14 @@ __global__ __launch_bounds__(64 * WPB, RCM_PAIR_LB) void k_rt_lbl_pair(Dev d) {
   }
   __syncthreads();
 
+  // reciprocal of the column's coldest / warmest temperature (for the once-per-band Planck regime test)
+  double rTmin = 0.0, rTmax = 1e300;
+  for (int k = 0; k <= NH; ++k) {
+    rTmin = fmax(rTmin, fmax(s.rT[0][k], s.rT[1][k]));
+    rTmax = fmin(rTmax, fmin(s.rT[0][k], s.rT[1][k]));
+  }
+  if (!(rTmax > 0.0)) rTmax = 0.0;  // T < 1e-4 or NaN somewhere: never the fast path
+
   // even lane: acc1[j] = E_down[j] (j = 0..10), acc2[k] = E_up[k] (k = 0..9)
   // odd lane:  acc1[j] = E_up[20-j] (j = 0..10), acc2[k] = E_down[20-k] (k = 0..9)
   double acc1[NH + 1], acc2[NH];
@@ -473,12 +481,25 @@ __global__ __launch_bounds__(64 * WPB, RCM_PAIR_LB) void k_rt_lbl_pair(Dev d) {
     const double wnumlo = 1.0E7 / d.lbl_wvl[b + 1];  // cplkavg.cpp:142
     const double c2lo = 1.438786 * wnumlo, c2hi = 1.438786 * wnumhi;  // cplkavg.cpp:152-153
     const bool narrow = (wnumhi - wnumlo) / wnumhi < 1.e-2;           // cplkavg.cpp:155
+    // Is every one of the column's 21 temperatures in the narrow-band regime for this lane's band
+    // (hh = (c2hi-c2lo)/T < kHhFast, eps < v < 700)?  Decided once per band from Tmin/Tmax with a 0.1 %
+    // margin; when the whole wave agrees the Planck loop runs branch-free.
+    const bool lane_fast = narrow && (c2hi - c2lo) * rTmin < 0.999 * kHhFast && c2hi * rTmin < 699.0 &&
+                           c2lo * rTmax > 1e-15;
+    if (__all(lane_fast)) {
 #pragma unroll RCM_PAIR_PLK_UNROLL
-    for (int k = 0; k <= NH; ++k) {
-      double Bk;
-      if (!(narrow && cplkavg_fast(c2lo, c2hi, s.T[p][k], s.rT[p][k], s.pc[p][k], &Bk)))
-        Bk = cplkavg_slow(wnumlo, wnumhi, s.T[p][k], s.tp[p][k]);
-      st[k][lane] = Bk;
+      for (int k = 0; k <= NH; ++k) {
+        const double t = s.T[p][k], rT = s.rT[p][k];
+        st[k][lane] = cplkavg_fast_eval(div_by_t(c2lo, t, rT), div_by_t(c2hi, t, rT), s.pc[p][k]);
+      }
+    } else {
+#pragma unroll 1
+      for (int k = 0; k <= NH; ++k) {
+        double Bk;
+        if (!(narrow && cplkavg_fast(c2lo, c2hi, s.T[p][k], s.rT[p][k], s.pc[p][k], &Bk)))
+          Bk = cplkavg_slow(wnumlo, wnumhi, s.T[p][k], s.tp[p][k]);
+        st[k][lane] = Bk;
+      }
     }
     double B[NH];
 #pragma unroll
