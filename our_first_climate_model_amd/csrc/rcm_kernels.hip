@@ -38,6 +38,9 @@ constexpr int WPB = 4;       // waves per block = columns per block (one per SIM
 #ifndef RCM_PAIR_LB
 #define RCM_PAIR_LB 2  // waves per SIMD the lane-pair lbl kernel is register-allocated for
 #endif
+#ifndef RCM_PLK_HOIST
+#define RCM_PLK_HOIST 1  // decide the Planck regime once per band (wave vote) and run the loop branch-free
+#endif
 #ifndef RCM_PAIR_PLK_UNROLL
 #define RCM_PAIR_PLK_UNROLL 3  // band-Planck evaluations in flight in the branch-free loop of the lane-pair lbl kernel
 #endif
@@ -486,7 +489,7 @@ __global__ __launch_bounds__(64 * WPB, RCM_PAIR_LB) void k_rt_lbl_pair(Dev d) {
     // margin; when the whole wave agrees the Planck loop runs branch-free.
     const bool lane_fast = narrow && (c2hi - c2lo) * rTmin < 0.999 * kHhFast && c2hi * rTmin < 699.0 &&
                            c2lo * rTmax > 1e-15;
-    if (__all(lane_fast)) {
+    if (RCM_PLK_HOIST && __all(lane_fast)) {
 #pragma unroll RCM_PAIR_PLK_UNROLL
       for (int k = 0; k <= NH; ++k) {
         const double t = s.T[p][k], rT = s.rT[p][k];
