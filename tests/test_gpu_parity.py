@@ -452,3 +452,49 @@ def test_driver_restart_cache_equilibrium_and_column_selection(pkg, olib, golden
         os.remove(tmp_path / f"lbl.{name}.asc")  # second run must come from the cache alone
     _run_driver(lbl + ["--output", "l2.txt"], tmp_path)
     assert (tmp_path / "l1.txt").read_text() == (tmp_path / "l2.txt").read_text()
+
+
+def test_full_spectrum_step_is_consistent_with_its_own_fluxes(pkg, big):
+    # size-independent identities of main.cpp:337-341, 156-176 on the full 131 071-band ensemble:
+    # dE from the flux profiles, solar heating entering the lowest layer linearly, dt from the SIGNED max,
+    # T_new = T_adjusted + dE*dt*g/(c_air*dp*100), T_surface = theta of the lowest layer.
+    g = H.gpu_ensemble(pkg, big)
+    g.step(1)
+    Tadj = np.array([g.get_profile(c)[0] for c in range(8)])  # adjusted profile the second step will use
+    g.step(1)
+    f, s = g.get_fluxes(), g.get_state()
+    Ed, Eu, dE = f["E_down"], f["E_up"], f["dE"]
+    want = Ed[:, :-1] - Ed[:, 1:] + Eu[:, 1:] - Eu[:, :-1]
+    want[:, -1] += big["solar"] + Ed[:, -1] - Eu[:, -1]
+    np.testing.assert_allclose(dE, want, rtol=0, atol=1e-10)
+    dt = np.minimum(5.0 / dE.max(axis=1) * (1004 * 50.0 * 100.0) / 9.80665, 43200.0)
+    np.testing.assert_allclose(s["timestep"], dt, rtol=1e-14)
+    Tnew = Tadj + dE * dt[:, None] * 9.80665 / (1004 * 50.0 * 100.0)
+    np.testing.assert_allclose(s["Tlayer"], Tnew, rtol=0, atol=1e-11)
+    np.testing.assert_allclose(s["T_surface"], s["Tlayer"][:, -1] * big["cols"]["conv"][-1], rtol=1e-15)
+    g2 = H.gpu_ensemble(pkg, big)
+    g2.set_forcing(big["solar"] + 10.0)
+    g2.step(1)
+    g1 = H.gpu_ensemble(pkg, big)
+    g1.step(1)
+    d = g2.get_fluxes()["dE"] - g1.get_fluxes()["dE"]
+    assert np.all(d[:, :-1] == 0.0) and np.allclose(d[:, -1], 10.0, rtol=0, atol=1e-10)
+
+
+def test_bench_contract_on_a_small_workload(pkg):
+    import json
+    import subprocess
+    import sys
+    r = subprocess.run([sys.executable, os.path.join(H.ROOT, "bench.py"), "--ncol", "64", "--nodes", "4097", "--steps",
+                        "2", "--warmup", "1"], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+              "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert k in d, k
+    assert d["n_gpus"] == 1 and d["steps"] == 2 and d["dtype"] == "f64" and d["vs_baseline"] is None
+    assert set(("bound", "achieved", "peak", "unit", "frac", "traffic")) <= set(d["roofline"])
+    assert abs(d["roofline"]["frac"] - d["roofline"]["achieved"] / d["roofline"]["peak"]) < 1e-12
+    assert d["cpu_baseline"]["kind"] == "port" and d["cpu_baseline"]["cores"] >= 1 and d["value"] > 0
