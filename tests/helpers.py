@@ -35,8 +35,8 @@ def configure(e, inp):
     return e
 
 
-def oracle_ensemble(olib, inp, threads=8):
-    e = ol.OracleEnsemble(olib, inp["ncol"])
+def oracle_ensemble(olib, inp, threads=8, nangle=30):
+    e = ol.OracleEnsemble(olib, inp["ncol"], nangle=nangle)
     configure(e, inp)
     e.set_threads(threads)
     return e

@@ -498,3 +498,15 @@ def test_bench_contract_on_a_small_workload(pkg):
     assert set(("bound", "achieved", "peak", "unit", "frac", "traffic")) <= set(d["roofline"])
     assert abs(d["roofline"]["frac"] - d["roofline"]["achieved"] / d["roofline"]["peak"]) < 1e-12
     assert d["cpu_baseline"]["kind"] == "port" and d["cpu_baseline"]["cores"] >= 1 and d["value"] > 0
+
+
+@pytest.mark.parametrize("nangle", [1, 2, 8, 13, 41, 64])
+def test_other_angle_counts(pkg, olib, nangle):
+    # main.cpp:80 compiles 30 angles in; the ABI takes 1..64.  The cube chains (t_{n/3} = t_n^3) must hold for
+    # every 2*nangle-1: e.g. 13 angles -> roots 9..25 and chains 9->3->1, 15->5, 21->7; 41 -> 81->27->9->3->1.
+    for mode, kw in (("repwvl", dict(table="Reduced20")), ("lbl", dict(n_nodes=300, atm="fpda.lbl.atm"))):
+        inp = H.make_inputs(pkg, mode, 3, **kw)
+        g, o = H.gpu_ensemble(pkg, inp, nangle=nangle), H.oracle_ensemble(olib, inp, nangle=nangle)
+        g.step(2), o.step(2)
+        _check_fluxes(g, o)
+        _check_state(g, o)
