@@ -1,0 +1,766 @@
+// rcm_capi.hip -- the ensemble handle and the C ABI (include/rcm.h) on top of the gfx950 kernels of
+// rcm_kernels.hpp: device buffers, table upload and re-layout, launch geometry, step loop, getters,
+// restart files.  Host-only pieces of the reference driver live in rcm_host.cpp.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "rcm.h"
+#include "rcm_internal.hpp"
+#include "rcm_kernels.hpp"
+
+// =============================================================================================
+// Host side: the handle and the C ABI.
+// =============================================================================================
+using rcm::Dev;
+using rcm::fail;
+using rcm::NL;
+using rcm::NLEV;
+
+#define HIPCK(call)                                                                       \
+  do {                                                                                    \
+    hipError_t e_ = (call);                                                               \
+    if (e_ != hipSuccess)                                                                 \
+      return fail(RCM_ERR_HIP, std::string(#call) + ": " + hipGetErrorString(e_));        \
+  } while (0)
+
+struct rcm_ensemble {
+  int ncol = 0, nlayer = 0, nangle = 0, device = 0, mode = rcm::MODE_NONE;
+  hipStream_t stream = nullptr;
+  bool own_stream = false;
+  bool have_grid = false, have_columns = false;
+  long long step_index = 0;  // the reference's loop variable i (main.cpp:531)
+  int user_chunks = 0;
+  int exp_variant = 1, cube = 1, planck_fast = 1, pair = 1;
+  std::vector<double> plevel, player, conv;
+  std::vector<void *> allocs;
+  Dev d{};
+  double *scratch = nullptr;  // 2*NL doubles
+  double *partial_buf = nullptr;
+  // repwvl host copies needed to (re)derive per-layer constants
+  std::vector<double> p_grid;
+  int *d_ip = nullptr;
+  double *d_delP = nullptr, *d_numDens = nullptr;
+  // timing
+  bool timing = false;
+  std::vector<std::pair<hipEvent_t, hipEvent_t>> events;
+  size_t events_used = 0;
+};
+
+namespace {
+
+template <typename T>
+int dev_alloc(rcm_ensemble *h, T **p, size_t n) {
+  void *q = nullptr;
+  HIPCK(hipMalloc(&q, (n ? n : 1) * sizeof(T)));
+  h->allocs.push_back(q);
+  *p = (T *)q;
+  return RCM_OK;
+}
+
+template <typename T>
+int dev_upload(rcm_ensemble *h, T **p, const T *src, size_t n) {
+  if (int rc = dev_alloc(h, p, n)) return rc;
+  HIPCK(hipMemcpyAsync(*p, src, n * sizeof(T), hipMemcpyHostToDevice, h->stream));
+  HIPCK(hipStreamSynchronize(h->stream));
+  return RCM_OK;
+}
+
+int use_device(rcm_ensemble *h) {
+  HIPCK(hipSetDevice(h->device));
+  return RCM_OK;
+}
+
+// Per-layer constants of read_tau that depend only on the pressure grid
+// (repwvl_thermal.cpp:68-73, 201-202, 214, 226, 240), top-first layer index.
+int derive_repwvl_layers(rcm_ensemble *h) {
+  if (h->mode != rcm::MODE_REPWVL || !h->have_grid) return RCM_OK;
+  const double avog = 6.02214076e23, molMassAir = 0.0289647, earthAccel = 9.80665;
+  std::vector<int> ip(NL);
+  std::vector<double> delP(NL), numDens(NL);
+  const int np = (int)h->p_grid.size();
+  for (int o = 0; o < NL; ++o) {
+    const double p_up = h->plevel[o] * 100.0, p_dn = h->plevel[o + 1] * 100.0;  // Pa
+    const double midP = (p_up + p_dn) / 2;                                       // :214
+    // LowerPos(p_ref, midP), :19-45
+    auto sgn = [](double v) { return (0.0 < v) - (v < 0.0); };
+    int lp = 0, sign = sgn(h->p_grid[0] - midP);
+    for (int p = 1; p != np; ++p) {
+      const double delta = h->p_grid[p] - midP;
+      if (sign != sgn(delta) || p == np - 1) {
+        lp = p - 1;
+        break;
+      }
+      sign = sgn(delta);
+    }
+    ip[o] = lp;
+    delP[o] = (midP - h->p_grid[lp]) / (h->p_grid[lp + 1] - h->p_grid[lp]);  // :240
+    numDens[o] = (p_dn - p_up) * avog / molMassAir / earthAccel;              // :202
+  }
+  HIPCK(hipMemcpyAsync(h->d_ip, ip.data(), NL * sizeof(int), hipMemcpyHostToDevice, h->stream));
+  HIPCK(hipMemcpyAsync(h->d_delP, delP.data(), NL * sizeof(double), hipMemcpyHostToDevice, h->stream));
+  HIPCK(hipMemcpyAsync(h->d_numDens, numDens.data(), NL * sizeof(double), hipMemcpyHostToDevice, h->stream));
+  HIPCK(hipStreamSynchronize(h->stream));
+  return RCM_OK;
+}
+
+// Spectral chunking.  Pure function of (ncol, nspec, user override); measured on the MI355X
+// (tools/time_single.py, tools/chunk_sweep.sh):
+//  * a wave needs ~8 passes of 32 points to amortise its column prologue (64 columns: 512 chunks beat
+//    4096 by 7 %), so big ensembles use chunks of >= 8 passes, as many as give ~2.6e5 waves in flight
+//    (10 000 columns: 27-32 chunks beat 4 by 4 %: shorter tail, better balance);
+//  * a small ensemble must first fill the chip (3072 resident waves, a lone wave reaches ~1/6 of the
+//    VALU issue rate): down to 2 passes per wave until there are ~4 rounds of waves.
+void choose_chunks(int ncol, int nspec, int user_chunks, int *nchunk_out, int *chunk_len_out) {
+  const int rows = (nspec + 31) / 32;  // a lane-pair wave covers 32 spectral points per pass
+  long nchunk;
+  if (user_chunks > 0) {
+    nchunk = user_chunks;
+  } else {
+    const long fill = (12288L + ncol - 1) / ncol;          // chunks that give 4 rounds of resident waves
+    const long amortised = rows / 8 > 0 ? rows / 8 : 1;    // chunks of 8 passes
+    if (fill >= amortised) {
+      nchunk = fill;
+      if (nchunk > rows / 2) nchunk = rows / 2;            // keep two passes per wave
+    } else {
+      nchunk = (262144L + ncol - 1) / ncol;
+      if (nchunk > amortised) nchunk = amortised;
+    }
+  }
+  if (nchunk > rows) nchunk = rows;
+  if (nchunk < 1) nchunk = 1;
+  const int rows_per_chunk = (int)((rows + nchunk - 1) / nchunk);
+  *chunk_len_out = rows_per_chunk * 32;
+  *nchunk_out = (rows + rows_per_chunk - 1) / rows_per_chunk;
+}
+
+int ensure_partials(rcm_ensemble *h) {
+  choose_chunks(h->ncol, h->d.nspec, h->user_chunks, &h->d.nchunk, &h->d.chunk_len);
+  if (h->partial_buf) {
+    HIPCK(hipStreamSynchronize(h->stream));
+    HIPCK(hipFree(h->partial_buf));
+    h->partial_buf = nullptr;
+  }
+  HIPCK(hipMalloc((void **)&h->partial_buf, (size_t)h->ncol * h->d.nchunk * rcm::PSTRIDE * sizeof(double)));
+  h->d.partial = h->partial_buf;
+  return RCM_OK;
+}
+
+template <int EXPV, int CUBE>
+void launch_rt(rcm_ensemble *h, int blocks) {
+  if (h->mode == rcm::MODE_LBL && EXPV == 1 && h->planck_fast && h->pair) {
+    hipLaunchKernelGGL((rcm::k_rt_lbl_pair<CUBE>), dim3(blocks), dim3(64 * rcm::WPB), 0, h->stream, h->d);
+  } else if (h->mode == rcm::MODE_LBL) {
+#ifndef RCM_EXPERIMENT
+    if (!h->planck_fast)
+      hipLaunchKernelGGL((rcm::k_rt_lbl<EXPV, CUBE, 0>), dim3(blocks), dim3(64 * rcm::WPB), 0, h->stream, h->d);
+    else
+#endif
+      hipLaunchKernelGGL((rcm::k_rt_lbl<EXPV, CUBE, 1>), dim3(blocks), dim3(64 * rcm::WPB), 0, h->stream, h->d);
+  } else if (EXPV == 1 && h->pair) {
+    hipLaunchKernelGGL((rcm::k_rt_repwvl_pair<CUBE>), dim3(blocks), dim3(64 * rcm::WPB), 0, h->stream, h->d);
+  } else {
+    hipLaunchKernelGGL((rcm::k_rt_repwvl<EXPV, CUBE>), dim3(blocks), dim3(64 * rcm::WPB), 0, h->stream, h->d);
+  }
+}
+
+int launch_step(rcm_ensemble *h) {
+  Dev &d = h->d;
+  const int first = (h->step_index == 0) ? 1 : 0;
+  hipLaunchKernelGGL(rcm::k_pre, dim3((h->ncol + 127) / 128), dim3(128), 0, h->stream, d, first);
+  const int blocks = (int)(((long)h->ncol * d.nchunk + rcm::WPB - 1) / rcm::WPB);
+  hipEvent_t e0 = nullptr, e1 = nullptr;
+  if (h->timing) {
+    if (h->events_used == h->events.size()) {
+      hipEvent_t a, b;
+      HIPCK(hipEventCreate(&a));
+      HIPCK(hipEventCreate(&b));
+      h->events.emplace_back(a, b);
+    }
+    e0 = h->events[h->events_used].first;
+    e1 = h->events[h->events_used].second;
+    ++h->events_used;
+    HIPCK(hipEventRecord(e0, h->stream));
+  }
+#ifdef RCM_EXPERIMENT  // quick A/B builds: only the EXPV = 1 instantiations
+  if (!h->cube)
+    launch_rt<1, 0>(h, blocks);
+  else
+    launch_rt<1, 1>(h, blocks);
+#else
+  if (h->exp_variant == 0 && !h->cube)
+    launch_rt<0, 0>(h, blocks);
+  else if (h->exp_variant == 0 && h->cube)
+    launch_rt<0, 1>(h, blocks);
+  else if (h->exp_variant == 1 && !h->cube)
+    launch_rt<1, 0>(h, blocks);
+  else
+    launch_rt<1, 1>(h, blocks);
+#endif
+  if (h->timing) HIPCK(hipEventRecord(e1, h->stream));
+  int post_waves = d.nchunk / 16;  // waves per column in k_post: one per 16 chunk partials, 1..16
+  post_waves = post_waves < 1 ? 1 : (post_waves > 16 ? 16 : post_waves);
+  hipLaunchKernelGGL(rcm::k_post, dim3(h->ncol), dim3(64 * post_waves), 0, h->stream, d);
+  HIPCK(hipGetLastError());
+  ++h->step_index;
+  return RCM_OK;
+}
+
+}  // namespace
+
+// ---- restart file: "RCMCKPT1", int64 {ncol, nlayer, ngas, mode, step_index}, then the arrays ----
+namespace {
+struct CkptField {
+  void *dev;
+  size_t bytes;
+};
+std::vector<CkptField> ckpt_fields(rcm_ensemble *h) {
+  const Dev &d = h->d;
+  const size_t nc = (size_t)h->ncol, nT = nc * NL;
+  return {{d.T, nT * 8},           {d.Ttau, nT * 8},
+          {d.Tsfc, nc * 8},        {d.dt, nc * 8},
+          {d.time_h, nc * 4},      {d.gas, nT * d.ngas * 8},
+          {(void *)d.rel_hum, nT * 8}, {(void *)d.solar_irr, nc * 8},
+          {(void *)d.cloud_tau, nc * 8}, {(void *)d.cloud_layer, nc * 4},
+          {d.E_down, nc * NLEV * 8}, {d.E_up, nc * NLEV * 8},
+          {d.dE, nT * 8},          {d.resid, nc * 8},
+          {d.Tprev, nT * 8}};
+}
+}  // namespace
+
+extern "C" {
+
+int rcm_create(int ncol, int nlayer, int nangle, int device, void *stream, rcm_ensemble **out) {
+  if (!out) return fail(RCM_ERR_ARG, "rcm_create: out is NULL");
+  *out = nullptr;
+  if (ncol < 1) return fail(RCM_ERR_ARG, "rcm_create: ncol must be >= 1");
+  if (nlayer != NL) return fail(RCM_ERR_ARG, "rcm_create: kernels are specialised for nlayer == 20 (main.cpp:78)");
+  if (nangle < 1 || nangle > 64) return fail(RCM_ERR_ARG, "rcm_create: nangle must be in 1..64");
+  int ndev = 0;
+  hipError_t e = hipGetDeviceCount(&ndev);
+  if (e != hipSuccess || ndev < 1)
+    return fail(RCM_ERR_HIP, std::string("rcm_create: no HIP device (this library has no CPU path): hipGetDeviceCount -> ") +
+                                 hipGetErrorString(e) + ", count " + std::to_string(ndev));
+  if (device < 0 || device >= ndev) return fail(RCM_ERR_ARG, "rcm_create: device index out of range");
+  rcm_ensemble *h = new (std::nothrow) rcm_ensemble();
+  if (!h) return fail(RCM_ERR_NOMEM, "rcm_create: out of memory");
+  h->ncol = ncol, h->nlayer = nlayer, h->nangle = nangle, h->device = device;
+  if (const char *v = std::getenv("RCM_EXP_VARIANT")) h->exp_variant = std::atoi(v) ? 1 : 0;
+  if (const char *v = std::getenv("RCM_CUBE")) h->cube = std::atoi(v) ? 1 : 0;
+  if (const char *v = std::getenv("RCM_PLANCK_FAST")) h->planck_fast = std::atoi(v) ? 1 : 0;
+  if (const char *v = std::getenv("RCM_PAIR")) h->pair = std::atoi(v) ? 1 : 0;
+  auto bail = [&](int rc) {
+    rcm_destroy(h);
+    return rc;
+  };
+  if (int rc = use_device(h)) return bail(rc);
+  if (stream) {
+    h->stream = (hipStream_t)stream;
+  } else {
+    if (hipStreamCreate(&h->stream) != hipSuccess) return bail(fail(RCM_ERR_HIP, "hipStreamCreate failed"));
+    h->own_stream = true;
+  }
+  Dev &d = h->d;
+  d.ncol = ncol, d.nangle = nangle, d.mode = rcm::MODE_NONE;
+  d.dp = 1000.0 / (double)nlayer;  // main.cpp:355
+  d.sigdpi = 5.67032E-8 / M_PI;    // cplkavg.cpp:121,134
+  const size_t nT = (size_t)ncol * NL, nE = (size_t)ncol * NLEV;
+  int rc = 0;
+  rc = rc ? rc : dev_alloc(h, &d.T, nT);
+  rc = rc ? rc : dev_alloc(h, &d.Ttau, nT);
+  rc = rc ? rc : dev_alloc(h, &d.Tsfc, (size_t)ncol);
+  rc = rc ? rc : dev_alloc(h, &d.dt, (size_t)ncol);
+  rc = rc ? rc : dev_alloc(h, &d.time_h, (size_t)ncol);
+  rc = rc ? rc : dev_alloc(h, (double **)&d.rel_hum, nT);
+  rc = rc ? rc : dev_alloc(h, &d.E_down, nE);
+  rc = rc ? rc : dev_alloc(h, &d.E_up, nE);
+  rc = rc ? rc : dev_alloc(h, &d.dE, nT);
+  rc = rc ? rc : dev_alloc(h, &h->scratch, (size_t)2 * NL);
+  rc = rc ? rc : dev_alloc(h, (double **)&d.solar_irr, (size_t)ncol);
+  rc = rc ? rc : dev_alloc(h, (double **)&d.cloud_tau, (size_t)ncol);
+  rc = rc ? rc : dev_alloc(h, (int **)&d.cloud_layer, (size_t)ncol);
+  rc = rc ? rc : dev_alloc(h, &d.resid, (size_t)ncol);
+  rc = rc ? rc : dev_alloc(h, &d.Tprev, nT);
+  rc = rc ? rc : dev_alloc(h, (double **)&d.player, (size_t)NL);
+  rc = rc ? rc : dev_alloc(h, (double **)&d.conv, (size_t)NL);
+  rc = rc ? rc : dev_alloc(h, &h->d_ip, (size_t)NL);
+  rc = rc ? rc : dev_alloc(h, &h->d_delP, (size_t)NL);
+  rc = rc ? rc : dev_alloc(h, &h->d_numDens, (size_t)NL);
+  if (rc) return bail(rc);
+  d.ip = h->d_ip, d.delP = h->d_delP, d.numDens = h->d_numDens;
+  // angles: mu_i = dmu/2 + dmu*i (main.cpp:356,482); weight 2*pi*mu*dmu (main.cpp:302,308,313)
+  std::vector<double> ang(2 * (size_t)nangle);
+  const double dmu = 1.0 / (double)nangle;
+  for (int i = 0; i < nangle; ++i) {
+    const double mu = dmu / 2.0 + dmu * (double)i;
+    ang[i] = 1.0 / mu;
+    ang[nangle + i] = 2 * M_PI * mu * dmu;
+  }
+  if ((rc = dev_upload(h, (double **)&d.ang, ang.data(), ang.size()))) return bail(rc);
+  hipError_t me = hipMemsetAsync(d.time_h, 0, ncol * sizeof(float), h->stream);
+  if (me == hipSuccess) me = hipMemsetAsync(d.dt, 0, ncol * sizeof(double), h->stream);
+  if (me == hipSuccess) me = hipMemsetAsync(d.E_down, 0, nE * sizeof(double), h->stream);
+  if (me == hipSuccess) me = hipMemsetAsync(d.E_up, 0, nE * sizeof(double), h->stream);
+  if (me == hipSuccess) me = hipMemsetAsync(d.dE, 0, nT * sizeof(double), h->stream);
+  if (me == hipSuccess) me = hipMemsetAsync(d.resid, 0, ncol * sizeof(double), h->stream);
+  if (me == hipSuccess) me = hipMemsetAsync(d.Tprev, 0, nT * sizeof(double), h->stream);
+  if (me == hipSuccess) me = hipStreamSynchronize(h->stream);
+  if (me != hipSuccess) return bail(fail(RCM_ERR_HIP, std::string("rcm_create: ") + hipGetErrorString(me)));
+  // the reference's compiled-in forcing until the caller says otherwise: cloud in layer 17 with
+  // tau_s/2 = 1.0 (main.cpp:86,92,267), solar heating 0
+  if ((rc = rcm_set_forcing(h, 0.0, 17, 2.0 / 2.0))) return bail(rc);
+  *out = h;
+  return RCM_OK;
+}
+
+int rcm_destroy(rcm_ensemble *h) {
+  if (!h) return fail(RCM_ERR_ARG, "rcm_destroy: NULL handle");
+  (void)hipSetDevice(h->device);
+  if (h->stream) (void)hipStreamSynchronize(h->stream);
+  for (void *p : h->allocs) (void)hipFree(p);
+  if (h->partial_buf) (void)hipFree(h->partial_buf);
+  for (auto &ev : h->events) {
+    (void)hipEventDestroy(ev.first);
+    (void)hipEventDestroy(ev.second);
+  }
+  if (h->own_stream && h->stream) (void)hipStreamDestroy(h->stream);
+  delete h;
+  return RCM_OK;
+}
+
+int rcm_set_grid(rcm_ensemble *h, const double *plevel_hPa) {
+  if (!h || !plevel_hPa) return fail(RCM_ERR_ARG, "rcm_set_grid: bad argument");
+  if (int rc = use_device(h)) return rc;
+  h->plevel.assign(plevel_hPa, plevel_hPa + NLEV);
+  h->player.resize(NL);
+  h->conv.resize(NL);
+  for (int i = 0; i < NL; ++i) {
+    h->player[i] = (plevel_hPa[i] + plevel_hPa[i + 1]) / 2.0;  // main.cpp:472
+    if (!(h->player[i] > 0)) return fail(RCM_ERR_ARG, "rcm_set_grid: layer pressure must be positive");
+    h->conv[i] = std::pow(1000.0 / h->player[i], 2.0 / 7.0);   // main.cpp:474, kappa main.cpp:66
+  }
+  HIPCK(hipMemcpyAsync((void *)h->d.player, h->player.data(), NL * sizeof(double), hipMemcpyHostToDevice, h->stream));
+  HIPCK(hipMemcpyAsync((void *)h->d.conv, h->conv.data(), NL * sizeof(double), hipMemcpyHostToDevice, h->stream));
+  HIPCK(hipStreamSynchronize(h->stream));
+  h->have_grid = true;
+  return derive_repwvl_layers(h);
+}
+
+int rcm_set_forcing(rcm_ensemble *h, double solar_irr, int cloud_layer, double cloud_tau) {
+  if (!h || cloud_layer < -1 || cloud_layer >= NL) return fail(RCM_ERR_ARG, "rcm_set_forcing: bad argument");
+  if (int rc = use_device(h)) return rc;
+  std::vector<double> a((size_t)h->ncol, solar_irr), b((size_t)h->ncol, cloud_tau);
+  std::vector<int> c((size_t)h->ncol, cloud_layer);
+  return rcm_set_column_forcing(h, a.data(), c.data(), b.data());
+}
+
+int rcm_set_column_forcing(rcm_ensemble *h, const double *solar_irr, const int *cloud_layer, const double *cloud_tau) {
+  if (!h) return fail(RCM_ERR_ARG, "rcm_set_column_forcing: NULL handle");
+  if (cloud_layer)
+    for (int c = 0; c < h->ncol; ++c)
+      if (cloud_layer[c] < -1 || cloud_layer[c] >= NL)
+        return fail(RCM_ERR_ARG, "rcm_set_column_forcing: cloud_layer must be in -1..nlayer-1");
+  if (int rc = use_device(h)) return rc;
+  const size_t n = (size_t)h->ncol;
+  if (solar_irr)
+    HIPCK(hipMemcpyAsync((void *)h->d.solar_irr, solar_irr, n * sizeof(double), hipMemcpyHostToDevice, h->stream));
+  if (cloud_layer)
+    HIPCK(hipMemcpyAsync((void *)h->d.cloud_layer, cloud_layer, n * sizeof(int), hipMemcpyHostToDevice, h->stream));
+  if (cloud_tau)
+    HIPCK(hipMemcpyAsync((void *)h->d.cloud_tau, cloud_tau, n * sizeof(double), hipMemcpyHostToDevice, h->stream));
+  HIPCK(hipStreamSynchronize(h->stream));
+  return RCM_OK;
+}
+
+int rcm_solar_setup_columns(rcm_ensemble *h, const double *tau_s, const double *mu_s, const double *albedo,
+                            int doublings, double g_asym, double daytime, double E_0, double *solar_out) {
+  if (!h || !tau_s || !mu_s || !albedo || doublings < 0)
+    return fail(RCM_ERR_ARG, "rcm_solar_setup_columns: bad argument");
+  for (int c = 0; c < h->ncol; ++c)
+    if (!(mu_s[c] > 0)) return fail(RCM_ERR_ARG, "rcm_solar_setup_columns: mu_s must be positive");
+  if (int rc = use_device(h)) return rc;
+  const size_t n = (size_t)h->ncol;
+  double *buf = nullptr;
+  HIPCK(hipMalloc((void **)&buf, n * 10 * sizeof(double)));
+  double *d_tau = buf, *d_mu = buf + n, *d_alb = buf + 2 * n, *d_out = buf + 3 * n;
+  hipError_t e = hipMemcpyAsync(d_tau, tau_s, n * sizeof(double), hipMemcpyHostToDevice, h->stream);
+  if (e == hipSuccess) e = hipMemcpyAsync(d_mu, mu_s, n * sizeof(double), hipMemcpyHostToDevice, h->stream);
+  if (e == hipSuccess) e = hipMemcpyAsync(d_alb, albedo, n * sizeof(double), hipMemcpyHostToDevice, h->stream);
+  if (e == hipSuccess) {
+    hipLaunchKernelGGL(rcm::k_solar, dim3((unsigned)((n + 127) / 128)), dim3(128), 0, h->stream, h->ncol, d_tau, d_mu,
+                       d_alb, doublings, g_asym, daytime, E_0, (double *)h->d.solar_irr, (double *)h->d.cloud_tau,
+                       d_out);
+    e = hipGetLastError();
+  }
+  if (e == hipSuccess && solar_out)
+    e = hipMemcpyAsync(solar_out, d_out, n * 7 * sizeof(double), hipMemcpyDeviceToHost, h->stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+  (void)hipFree(buf);
+  if (e != hipSuccess) return fail(RCM_ERR_HIP, std::string("rcm_solar_setup_columns: ") + hipGetErrorString(e));
+  return RCM_OK;
+}
+
+int rcm_get_residual(rcm_ensemble *h, double *resid) {
+  if (!h || !resid) return fail(RCM_ERR_ARG, "rcm_get_residual: bad argument");
+  if (int rc = use_device(h)) return rc;
+  HIPCK(hipMemcpyAsync(resid, h->d.resid, (size_t)h->ncol * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  HIPCK(hipStreamSynchronize(h->stream));
+  return RCM_OK;
+}
+
+int rcm_run_to_equilibrium(rcm_ensemble *h, double tol_K, int max_steps, int check_every, int *steps_done,
+                           double *residual_K) {
+  if (!h || !(tol_K >= 0) || max_steps < 0 || check_every < 1)
+    return fail(RCM_ERR_ARG, "rcm_run_to_equilibrium: bad argument");
+  std::vector<double> r((size_t)h->ncol);
+  int done = 0;
+  double worst = HUGE_VAL;
+  while (done < max_steps) {
+    const int n = std::min(check_every, max_steps - done);
+    if (int rc = rcm_step(h, n)) return rc;
+    done += n;
+    if (int rc = rcm_get_residual(h, r.data())) return rc;
+    worst = 0.0;
+    for (double v : r) worst = (v > worst || v != v) ? v : worst;
+    if (worst <= tol_K) break;
+  }
+  if (steps_done) *steps_done = done;
+  if (residual_K) *residual_K = worst;
+  return RCM_OK;
+}
+
+int rcm_set_repwvl_tables(rcm_ensemble *h, int n_tpert, int n_species, int n_wvl, int n_p,
+                          const double *p_grid, const double *t_ref, const double *t_pert,
+                          const double *wvl, const double *weight, const double *xsec) {
+  if (!h || !p_grid || !t_ref || !t_pert || !wvl || !weight || !xsec)
+    return fail(RCM_ERR_ARG, "rcm_set_repwvl_tables: NULL argument");
+  if (n_species != RCM_NSPEC_REPWVL) return fail(RCM_ERR_ARG, "rcm_set_repwvl_tables: n_species must be 9");
+  if (n_tpert < 2 || n_p < 2 || n_wvl < 1) return fail(RCM_ERR_ARG, "rcm_set_repwvl_tables: bad dimensions");
+  if (h->mode != rcm::MODE_NONE) return fail(RCM_ERR_STATE, "rcm_set_repwvl_tables: tables already set");
+  if (int rc = use_device(h)) return rc;
+  Dev &d = h->d;
+  // re-lay out [t][s][w][p] -> [t][s][p][w] so that a wave's 64 wavelengths are contiguous
+  std::vector<double> xt((size_t)n_tpert * n_species * n_p * n_wvl);
+  for (int t = 0; t < n_tpert; ++t)
+    for (int s = 0; s < n_species; ++s)
+      for (int w = 0; w < n_wvl; ++w)
+        for (int p = 0; p < n_p; ++p)
+          xt[(((size_t)t * n_species + s) * n_p + p) * n_wvl + w] =
+              xsec[(((size_t)t * n_species + s) * n_wvl + w) * n_p + p];
+  // per-wavelength Planck constants in the reference's operation order (main.cpp:188-191)
+  std::vector<double> pnum(n_wvl), lam5(n_wvl), lkb(n_wvl);
+  const double hP = 6.62607e-34, cL = 299792458, kB = 1.380649e-23;  // main.cpp:70-72
+  for (int w = 0; w < n_wvl; ++w) {
+    double lam = wvl[w];
+    lam *= 1e-9;
+    pnum[w] = weight[w] * 2 * hP * std::pow(cL, 2);
+    lam5[w] = std::pow(lam, 5);
+    lkb[w] = lam * kB;
+  }
+  int rc = 0;
+  rc = rc ? rc : dev_upload(h, (double **)&d.xsec, xt.data(), xt.size());
+  rc = rc ? rc : dev_upload(h, (double **)&d.t_ref, t_ref, (size_t)n_p);
+  rc = rc ? rc : dev_upload(h, (double **)&d.t_pert, t_pert, (size_t)n_tpert);
+  rc = rc ? rc : dev_upload(h, (double **)&d.pnum, pnum.data(), (size_t)n_wvl);
+  rc = rc ? rc : dev_upload(h, (double **)&d.lam5, lam5.data(), (size_t)n_wvl);
+  rc = rc ? rc : dev_upload(h, (double **)&d.lkb, lkb.data(), (size_t)n_wvl);
+  if (rc) return rc;
+  h->p_grid.assign(p_grid, p_grid + n_p);
+  d.n_tpert = n_tpert, d.n_species = n_species, d.n_p = n_p, d.n_wvl = n_wvl;
+  d.nspec = n_wvl;
+  d.ngas = RCM_NSPEC_REPWVL;
+  d.mode = h->mode = rcm::MODE_REPWVL;
+  d.species_mask = 0x1ff;
+  return derive_repwvl_layers(h);
+}
+
+int rcm_set_lbl_tables(rcm_ensemble *h, int n_nodes, const double *wvl,
+                       const double *const tabs[RCM_NSPEC_LBL], const double *h2o_ref) {
+  if (!h || !wvl || !tabs || !h2o_ref) return fail(RCM_ERR_ARG, "rcm_set_lbl_tables: NULL argument");
+  if (n_nodes < 2) return fail(RCM_ERR_ARG, "rcm_set_lbl_tables: need at least 2 wavelength nodes");
+  for (int s = 0; s < RCM_NSPEC_LBL; ++s)
+    if (!tabs[s]) return fail(RCM_ERR_ARG, "rcm_set_lbl_tables: NULL species table");
+  for (int i = 0; i + 1 < n_nodes; ++i)  // cplkavg.cpp:144-146 would exit(1) on these
+    if (!(wvl[i] > 0) || !(wvl[i] < wvl[i + 1]))
+      return fail(RCM_ERR_ARG, "rcm_set_lbl_tables: wavelengths must be positive and strictly increasing");
+  for (int l = 0; l < NL; ++l)
+    if (!(h2o_ref[l] > 0)) return fail(RCM_ERR_ARG, "rcm_set_lbl_tables: h2o_ref must be positive");
+  if (h->mode != rcm::MODE_NONE) return fail(RCM_ERR_STATE, "rcm_set_lbl_tables: tables already set");
+  if (int rc = use_device(h)) return rc;
+  Dev &d = h->d;
+  const long nband = n_nodes - 1;
+  const long ld = (nband + 63) / 64 * 64;
+  double *tab = nullptr, *stage = nullptr;
+  if (int rc = dev_alloc(h, &tab, (size_t)RCM_NSPEC_LBL * NL * ld)) return rc;
+  HIPCK(hipMalloc((void **)&stage, (size_t)n_nodes * NL * sizeof(double)));
+  for (int s = 0; s < RCM_NSPEC_LBL; ++s) {
+    hipError_t e = hipMemcpyAsync(stage, tabs[s], (size_t)n_nodes * NL * sizeof(double), hipMemcpyHostToDevice, h->stream);
+    if (e == hipSuccess) {
+      hipLaunchKernelGGL(rcm::k_transpose_lbl, dim3((unsigned)(ld / 64)), dim3(256), 0, h->stream, stage,
+                         tab + (size_t)s * NL * ld, (long)n_nodes, ld);
+      e = hipStreamSynchronize(h->stream);
+    }
+    if (e != hipSuccess) {
+      (void)hipFree(stage);
+      return fail(RCM_ERR_HIP, std::string("rcm_set_lbl_tables: ") + hipGetErrorString(e));
+    }
+  }
+  (void)hipFree(stage);
+  int rc = 0;
+  rc = rc ? rc : dev_upload(h, (double **)&d.lbl_wvl, wvl, (size_t)n_nodes);
+  rc = rc ? rc : dev_upload(h, (double **)&d.h2o_ref, h2o_ref, (size_t)NL);
+  if (rc) return rc;
+  d.lbl_tab = tab;
+  d.lbl_ld = ld;
+  d.nspec = (int)nband;
+  d.ngas = RCM_NSPEC_LBL;
+  d.mode = h->mode = rcm::MODE_LBL;
+  return RCM_OK;
+}
+
+int rcm_set_columns(rcm_ensemble *h, const double *Tlayer0, const double *T_surface0,
+                    const double *gas, const double *rel_hum) {
+  if (!h || !Tlayer0 || !T_surface0 || !gas || !rel_hum) return fail(RCM_ERR_ARG, "rcm_set_columns: NULL argument");
+  if (h->mode == rcm::MODE_NONE) return fail(RCM_ERR_STATE, "rcm_set_columns: set the spectral tables first");
+  if (int rc = use_device(h)) return rc;
+  Dev &d = h->d;
+  const size_t nT = (size_t)h->ncol * NL, nG = nT * d.ngas;
+  if (!d.gas)
+    if (int rc = dev_alloc(h, &d.gas, nG)) return rc;
+  if (h->mode == rcm::MODE_REPWVL) {  // species whose mixing ratio is 0 everywhere add exactly +0
+    unsigned mask = 0;
+    for (int c = 0; c < h->ncol; ++c)
+      for (int s = 0; s < RCM_NSPEC_REPWVL; ++s)
+        for (int l = 0; l < NL; ++l)
+          if (gas[((size_t)c * RCM_NSPEC_REPWVL + s) * NL + l] != 0.0) mask |= 1u << s;
+    d.species_mask = mask | 1u;  // H2O always: the feedback rewrites it
+  }
+  HIPCK(hipMemcpyAsync(d.T, Tlayer0, nT * sizeof(double), hipMemcpyHostToDevice, h->stream));
+  HIPCK(hipMemcpyAsync(d.Ttau, Tlayer0, nT * sizeof(double), hipMemcpyHostToDevice, h->stream));
+  HIPCK(hipMemcpyAsync(d.Tsfc, T_surface0, h->ncol * sizeof(double), hipMemcpyHostToDevice, h->stream));
+  HIPCK(hipMemcpyAsync(d.gas, gas, nG * sizeof(double), hipMemcpyHostToDevice, h->stream));
+  HIPCK(hipMemcpyAsync((void *)d.rel_hum, rel_hum, nT * sizeof(double), hipMemcpyHostToDevice, h->stream));
+  HIPCK(hipMemsetAsync(d.time_h, 0, h->ncol * sizeof(float), h->stream));
+  HIPCK(hipMemsetAsync(d.dt, 0, h->ncol * sizeof(double), h->stream));
+  HIPCK(hipStreamSynchronize(h->stream));
+  h->step_index = 0;
+  h->have_columns = true;
+  return RCM_OK;
+}
+
+int rcm_set_spectral_chunks(rcm_ensemble *h, int nchunk) {
+  if (!h || nchunk < 0) return fail(RCM_ERR_ARG, "rcm_set_spectral_chunks: bad argument");
+  h->user_chunks = nchunk;
+  h->d.partial = nullptr;  // re-derive on the next step
+  return RCM_OK;
+}
+
+int rcm_get_spectral_chunks(rcm_ensemble *h) {
+  if (!h || h->mode == rcm::MODE_NONE) return fail(RCM_ERR_STATE, "rcm_get_spectral_chunks: tables not set");
+  int nchunk = 0, len = 0;
+  choose_chunks(h->ncol, h->d.nspec, h->user_chunks, &nchunk, &len);
+  return nchunk;
+}
+
+int rcm_step(rcm_ensemble *h, int nsteps) {
+  if (!h || nsteps < 0) return fail(RCM_ERR_ARG, "rcm_step: bad argument");
+  if (h->mode == rcm::MODE_NONE || !h->have_grid || !h->have_columns)
+    return fail(RCM_ERR_STATE, "rcm_step: grid, spectral tables and columns must be set first");
+  if (int rc = use_device(h)) return rc;
+  if (!h->d.partial)
+    if (int rc = ensure_partials(h)) return rc;
+  for (int i = 0; i < nsteps; ++i)
+    if (int rc = launch_step(h)) return rc;
+  return RCM_OK;
+}
+
+int rcm_sync(rcm_ensemble *h) {
+  if (!h) return fail(RCM_ERR_ARG, "rcm_sync: NULL handle");
+  if (int rc = use_device(h)) return rc;
+  HIPCK(hipStreamSynchronize(h->stream));
+  return RCM_OK;
+}
+
+static int copy_out(rcm_ensemble *h, void *dst, const void *src, size_t bytes) {
+  if (!dst) return RCM_OK;
+  HIPCK(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, h->stream));
+  return RCM_OK;
+}
+
+int rcm_get_state(rcm_ensemble *h, double *Tlayer, double *T_surface, float *time_h, double *timestep) {
+  if (!h) return fail(RCM_ERR_ARG, "rcm_get_state: NULL handle");
+  if (int rc = use_device(h)) return rc;
+  int rc = 0;
+  rc = rc ? rc : copy_out(h, Tlayer, h->d.T, (size_t)h->ncol * NL * sizeof(double));
+  rc = rc ? rc : copy_out(h, T_surface, h->d.Tsfc, h->ncol * sizeof(double));
+  rc = rc ? rc : copy_out(h, time_h, h->d.time_h, h->ncol * sizeof(float));
+  rc = rc ? rc : copy_out(h, timestep, h->d.dt, h->ncol * sizeof(double));
+  if (rc) return rc;
+  HIPCK(hipStreamSynchronize(h->stream));
+  return RCM_OK;
+}
+
+int rcm_get_fluxes(rcm_ensemble *h, double *E_down, double *E_up, double *dE) {
+  if (!h) return fail(RCM_ERR_ARG, "rcm_get_fluxes: NULL handle");
+  if (int rc = use_device(h)) return rc;
+  int rc = 0;
+  rc = rc ? rc : copy_out(h, E_down, h->d.E_down, (size_t)h->ncol * NLEV * sizeof(double));
+  rc = rc ? rc : copy_out(h, E_up, h->d.E_up, (size_t)h->ncol * NLEV * sizeof(double));
+  rc = rc ? rc : copy_out(h, dE, h->d.dE, (size_t)h->ncol * NL * sizeof(double));
+  if (rc) return rc;
+  HIPCK(hipStreamSynchronize(h->stream));
+  return RCM_OK;
+}
+
+int rcm_get_profile(rcm_ensemble *h, int col, double *Tlayer_adj, double *theta, float *time_h) {
+  if (!h || col < 0 || col >= h->ncol) return fail(RCM_ERR_ARG, "rcm_get_profile: bad argument");
+  if (!h->have_grid || !h->have_columns) return fail(RCM_ERR_STATE, "rcm_get_profile: grid/columns not set");
+  if (int rc = use_device(h)) return rc;
+  hipLaunchKernelGGL(rcm::k_profile, dim3(1), dim3(64), 0, h->stream, h->d, col, h->scratch);
+  HIPCK(hipGetLastError());
+  int rc = 0;
+  rc = rc ? rc : copy_out(h, Tlayer_adj, h->scratch, NL * sizeof(double));
+  rc = rc ? rc : copy_out(h, theta, h->scratch + NL, NL * sizeof(double));
+  rc = rc ? rc : copy_out(h, time_h, h->d.time_h + col, sizeof(float));
+  if (rc) return rc;
+  HIPCK(hipStreamSynchronize(h->stream));
+  return RCM_OK;
+}
+
+int rcm_nspectral(rcm_ensemble *h) {
+  if (!h || h->mode == rcm::MODE_NONE) return fail(RCM_ERR_STATE, "rcm_nspectral: tables not set");
+  return h->d.nspec;
+}
+
+int rcm_get_tau(rcm_ensemble *h, int col, double *tau) {
+  if (!h || !tau || col < 0 || col >= h->ncol) return fail(RCM_ERR_ARG, "rcm_get_tau: bad argument");
+  if (h->mode == rcm::MODE_NONE || !h->have_grid || !h->have_columns)
+    return fail(RCM_ERR_STATE, "rcm_get_tau: grid, tables and columns must be set first");
+  if (int rc = use_device(h)) return rc;
+  const size_t n = (size_t)h->d.nspec * NL;
+  double *buf = nullptr;
+  HIPCK(hipMalloc((void **)&buf, n * sizeof(double)));
+  hipLaunchKernelGGL(rcm::k_tau, dim3((h->d.nspec + 63) / 64), dim3(64), 0, h->stream, h->d, col, buf);
+  hipError_t e = hipGetLastError();
+  if (e == hipSuccess) e = hipMemcpyAsync(tau, buf, n * sizeof(double), hipMemcpyDeviceToHost, h->stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+  (void)hipFree(buf);
+  if (e != hipSuccess) return fail(RCM_ERR_HIP, std::string("rcm_get_tau: ") + hipGetErrorString(e));
+  return RCM_OK;
+}
+
+int rcm_get_gas(rcm_ensemble *h, double *gas) {
+  if (!h || !gas) return fail(RCM_ERR_ARG, "rcm_get_gas: bad argument");
+  if (!h->have_columns) return fail(RCM_ERR_STATE, "rcm_get_gas: columns not set");
+  if (int rc = use_device(h)) return rc;
+  if (int rc = copy_out(h, gas, h->d.gas, (size_t)h->ncol * h->d.ngas * NL * sizeof(double))) return rc;
+  HIPCK(hipStreamSynchronize(h->stream));
+  return RCM_OK;
+}
+
+int rcm_pack_state(rcm_ensemble *h, void *dev_out) {
+  if (!h || !dev_out) return fail(RCM_ERR_ARG, "rcm_pack_state: bad argument");
+  if (!h->have_columns) return fail(RCM_ERR_STATE, "rcm_pack_state: columns not set");
+  if (int rc = use_device(h)) return rc;
+  const size_t n = (size_t)h->ncol * NLEV;
+  hipLaunchKernelGGL(rcm::k_pack, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, h->stream, h->d, (double *)dev_out);
+  HIPCK(hipGetLastError());
+  return RCM_OK;
+}
+
+int rcm_checkpoint_save(rcm_ensemble *h, const char *path) {
+  if (!h || !path) return fail(RCM_ERR_ARG, "rcm_checkpoint_save: bad argument");
+  if (!h->have_columns) return fail(RCM_ERR_STATE, "rcm_checkpoint_save: columns not set");
+  if (int rc = use_device(h)) return rc;
+  FILE *f = std::fopen(path, "wb");
+  if (!f) return fail(RCM_ERR_IO, std::string("rcm_checkpoint_save: cannot open ") + path);
+  const long long hdr[5] = {h->ncol, NL, h->d.ngas, h->mode, h->step_index};
+  bool ok = std::fwrite("RCMCKPT1", 1, 8, f) == 8 && std::fwrite(hdr, sizeof(long long), 5, f) == 5;
+  std::vector<char> buf;
+  for (const auto &fld : ckpt_fields(h)) {
+    buf.resize(fld.bytes);
+    hipError_t e = hipMemcpyAsync(buf.data(), fld.dev, fld.bytes, hipMemcpyDeviceToHost, h->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+    if (e != hipSuccess) {
+      std::fclose(f);
+      return fail(RCM_ERR_HIP, std::string("rcm_checkpoint_save: ") + hipGetErrorString(e));
+    }
+    ok = ok && std::fwrite(buf.data(), 1, fld.bytes, f) == fld.bytes;
+  }
+  ok = (std::fclose(f) == 0) && ok;
+  return ok ? RCM_OK : fail(RCM_ERR_IO, std::string("rcm_checkpoint_save: write failed: ") + path);
+}
+
+int rcm_checkpoint_load(rcm_ensemble *h, const char *path) {
+  if (!h || !path) return fail(RCM_ERR_ARG, "rcm_checkpoint_load: bad argument");
+  if (h->mode == rcm::MODE_NONE || !h->have_grid)
+    return fail(RCM_ERR_STATE, "rcm_checkpoint_load: set the grid and the spectral tables first");
+  if (int rc = use_device(h)) return rc;
+  FILE *f = std::fopen(path, "rb");
+  if (!f) return fail(RCM_ERR_IO, std::string("rcm_checkpoint_load: cannot open ") + path);
+  char magic[8];
+  long long hdr[5];
+  if (std::fread(magic, 1, 8, f) != 8 || std::memcmp(magic, "RCMCKPT1", 8) != 0 ||
+      std::fread(hdr, sizeof(long long), 5, f) != 5) {
+    std::fclose(f);
+    return fail(RCM_ERR_FORMAT, std::string("rcm_checkpoint_load: not an RCMCKPT1 file: ") + path);
+  }
+  if (hdr[0] != h->ncol || hdr[1] != NL || hdr[2] != h->d.ngas || hdr[3] != h->mode || hdr[4] < 0) {
+    std::fclose(f);
+    return fail(RCM_ERR_ARG, "rcm_checkpoint_load: checkpoint does not match this ensemble (ncol/nlayer/species/mode)");
+  }
+  if (!h->d.gas)
+    if (int rc = dev_alloc(h, &h->d.gas, (size_t)h->ncol * NL * h->d.ngas)) {
+      std::fclose(f);
+      return rc;
+    }
+  std::vector<char> buf;
+  for (const auto &fld : ckpt_fields(h)) {
+    buf.resize(fld.bytes);
+    if (std::fread(buf.data(), 1, fld.bytes, f) != fld.bytes) {
+      std::fclose(f);
+      return fail(RCM_ERR_FORMAT, std::string("rcm_checkpoint_load: truncated file: ") + path);
+    }
+    hipError_t e = hipMemcpyAsync(fld.dev, buf.data(), fld.bytes, hipMemcpyHostToDevice, h->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+    if (e != hipSuccess) {
+      std::fclose(f);
+      return fail(RCM_ERR_HIP, std::string("rcm_checkpoint_load: ") + hipGetErrorString(e));
+    }
+  }
+  std::fclose(f);
+  h->step_index = hdr[4];
+  h->have_columns = true;
+  if (h->mode == rcm::MODE_REPWVL) h->d.species_mask = 0x1ff;  // unknown zero pattern: interpolate all nine
+  return RCM_OK;
+}
+
+int rcm_set_rt_timing(rcm_ensemble *h, int enable) {
+  if (!h) return fail(RCM_ERR_ARG, "rcm_set_rt_timing: NULL handle");
+  h->timing = enable != 0;
+  h->events_used = 0;
+  return RCM_OK;
+}
+
+int rcm_get_rt_timing(rcm_ensemble *h, double *ms_total, int *launches) {
+  if (!h) return fail(RCM_ERR_ARG, "rcm_get_rt_timing: NULL handle");
+  if (int rc = use_device(h)) return rc;
+  HIPCK(hipStreamSynchronize(h->stream));
+  double total = 0.0;
+  for (size_t i = 0; i < h->events_used; ++i) {
+    float ms = 0.f;
+    HIPCK(hipEventElapsedTime(&ms, h->events[i].first, h->events[i].second));
+    total += ms;
+  }
+  if (ms_total) *ms_total = total;
+  if (launches) *launches = (int)h->events_used;
+  h->events_used = 0;
+  return RCM_OK;
+}
+
+}  // extern "C"

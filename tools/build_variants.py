@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Builds experimental variants of librcm_hip.so (compile-time knobs of rcm_kernels.hip) into
+"""Builds experimental variants of librcm_hip.so (compile-time knobs of rcm_kernels.hpp) into
 our_first_climate_model_amd/variants/ for A/B runs on the GPU:
     python tools/build_variants.py name:-DRCM_LB=1,-DRCM_B_LDS=0 name2:...
 and tools/run_variants.py times each with tools/sweep_variants.py."""
@@ -20,7 +20,7 @@ def build(spec):
     so = os.path.join(OUT, f"librcm_hip_{name}.so")
     cmd = ["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "-fPIC", "--offload-arch=gfx950", "-DRCM_EXPERIMENT",
            "-I" + os.path.join(ROOT, "include"), "-I" + os.path.join(PKG, "csrc"), "-shared", "-o", so,
-           os.path.join(PKG, "csrc", "rcm_kernels.hip"), os.path.join(PKG, "csrc", "rcm_host.cpp"),
+           os.path.join(PKG, "csrc", "rcm_capi.hip"), os.path.join(PKG, "csrc", "rcm_host.cpp"),
            "-Rpass-analysis=kernel-resource-usage"] + flags
     r = subprocess.run(cmd, capture_output=True, text=True)
     if r.returncode != 0:
