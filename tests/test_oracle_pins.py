@@ -265,3 +265,45 @@ def test_lbl_binary_cache_round_trip(rcm, tmp_path):
     with pytest.raises(rcm.RcmError) as e:
         rcm.lbl_cache_read(p)
     assert e.value.code == -6
+
+
+def test_oracle_lbl_path_against_an_independent_numpy_statement(rcm, olib):
+    """The lbl composition has no reference driver ("parity unpinned" for the composition itself):
+    cross-check the C oracle against a second, array-level statement of the same rules written from the
+    documents (lbl.arts/README:5-17 format, main.cpp:297-344 sweep, cplkavg band source)."""
+    import helpers as H
+    inp = H.make_inputs(rcm, "lbl", 2, n_nodes=40, atm="fpda.lbl.atm")
+    o = H.oracle_ensemble(olib, inp, threads=1)
+    tau_o = o.get_tau(1)
+    c = inp["cols"]
+    gas = c["gas"][1]                                   # [5][20] multipliers
+    tabs = np.stack(inp["tabs"])                        # [5][nodes][20]
+    tau = np.einsum("sl,sbl->bl", gas, tabs[:, :-1, :])  # band b takes node b
+    tau[:, 17] += 1.0                                   # cloud_into_tau, main.cpp:266-274
+    np.testing.assert_allclose(tau_o, tau, rtol=1e-14, atol=0)
+    # one radiative_transfer call at the initial (already adjusted) state
+    T, Ts = c["Tlayer0"][1], c["T_surface0"][1]
+    wvl = inp["wvl"]
+    nb = wvl.size - 1
+    B = np.array([[olib.orc_cplkavg(wvl[b], wvl[b + 1], t) for t in T] for b in range(nb)])
+    Bs = np.array([olib.orc_cplkavg(wvl[b], wvl[b + 1], Ts) for b in range(nb)])
+    mu = (np.arange(30) + 0.5) / 30.0
+    w = 2 * np.pi * mu / 30.0
+    Ed, Eu = np.zeros(21), np.zeros(21)
+    t = np.exp(-tau[:, None, :] / mu[None, :, None])    # [band][angle][layer]
+    L = np.zeros((nb, 30))
+    for l in range(20):                                 # down, main.cpp:306-309
+        L = t[:, :, l] * L + (1 - t[:, :, l]) * B[:, None, l]
+        Ed[l + 1] = np.sum(L * w[None, :])
+    L = np.repeat(Bs[:, None], 30, axis=1)              # up, main.cpp:301-302, 311-314
+    Eu[20] = np.sum(L * w[None, :])
+    for l in range(19, -1, -1):
+        L = t[:, :, l] * L + (1 - t[:, :, l]) * B[:, None, l]
+        Eu[l] = np.sum(L * w[None, :])
+    o.step(1)
+    f = o.get_fluxes()
+    np.testing.assert_allclose(f["E_down"][1], Ed, rtol=0, atol=1e-11)
+    np.testing.assert_allclose(f["E_up"][1], Eu, rtol=0, atol=1e-11)
+    dE = Ed[:-1] - Ed[1:] + Eu[1:] - Eu[:-1]
+    dE[-1] += inp["solar"] + Ed[-1] - Eu[-1]
+    np.testing.assert_allclose(f["dE"][1], dE, rtol=0, atol=1e-11)
