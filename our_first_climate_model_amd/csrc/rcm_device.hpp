@@ -115,6 +115,12 @@ __device__ __forceinline__ double planck_mono(double pnum, double lam5, double l
   return pnum / (lam5 * (exp(kHC / (lkb * T)) - 1)) / 1e9;
 }
 
+// The same quantity for the lane-pair kernel, three IEEE divisions and a library exp cheaper:
+// per wavelength (once per pass) xc = h*c/(lambda*kB) and sc = pnum/lam5/1e9; per temperature
+// x = xc/T (correctly rounded through rT = 1/T), B = sc / (exp(x) - 1) with exp_pos and a
+// Newton-refined reciprocal.  Differs from planck_mono by a few 1e-16 relative.
+__device__ __forceinline__ double planck_mono_fast(double xc, double sc, double T, double rT);
+
 // ---------------------------------------------------------------------------------------------
 // Band-integrated Planck function: cplkavg.cpp:124-243 (libRadtran c_planck_func1).
 // Takes the wavenumber bounds (cplkavg.cpp:141-142 done by the caller, once per band) and
@@ -244,6 +250,14 @@ __device__ __forceinline__ bool cplkavg_fast(double c2lo, double c2hi, double t,
   if (!(hh < kHhFast && v0 > 2.2204460492503131e-16 && v1 < 700.0 && t >= 1.e-4)) return false;
   *out = cplkavg_fast_eval(v0, v1, pc);
   return true;
+}
+
+__device__ __forceinline__ double planck_mono_fast(double xc, double sc, double T, double rT) {
+  const double d = exp_pos(div_by_t(xc, T, rT)) - 1.0;
+  double g = __builtin_amdgcn_rcp(d);
+  g = fma(fma(-d, g, 1.0), g, g);
+  g = fma(fma(-d, g, 1.0), g, g);
+  return sc * g;
 }
 
 // Magnus saturation vapour pressure [hPa]: main.cpp:277-279

@@ -531,7 +531,8 @@ __global__ __launch_bounds__(64 * WPB, RCM_PAIR_LB) void k_rt_lbl_pair(Dev d) {
 // Same split as k_rt_lbl_pair: even lane = layers 0..9, odd lane = layers 19..10 of one wavelength.
 // ---------------------------------------------------------------------------------------------
 struct RepwvlPairLds {
-  double T[2][NH + 1];  // T[p][k] = Tlayer[layer(p,k)], k = NH: T_surface
+  double T[2][NH + 1];   // T[p][k] = Tlayer[layer(p,k)], k = NH: T_surface
+  double rT[2][NH + 1];  // 1/T
   double delT[2][NH], delP[2][NH], numDens[2][NH];
   double vmr[2][RCM_NSPEC_REPWVL][NH];
   int it[2][NH], ip[2][NH];
@@ -560,9 +561,11 @@ __global__ __launch_bounds__(64 * WPB, RCM_PAIR_LB) void k_rt_repwvl_pair(Dev d)
     const int q = lane / (NH + 1), k = lane - q * (NH + 1);
     if (k == NH) {
       s.T[q][k] = d.Tsfc[col];
+      s.rT[q][k] = 1.0 / d.Tsfc[col];
     } else {
       const int layer = q ? NL - 1 - k : k;
       s.T[q][k] = d.T[(size_t)col * NL + layer];
+      s.rT[q][k] = 1.0 / s.T[q][k];
       const double midT = d.Ttau[(size_t)col * NL + layer];  // :217 (prop_at_Lev == 0)
       const int ip = d.ip[layer];
       const double tr = d.t_ref[ip];
@@ -625,9 +628,10 @@ __global__ __launch_bounds__(64 * WPB, RCM_PAIR_LB) void k_rt_repwvl_pair(Dev d)
 #pragma unroll
     for (int k = 0; k < NH; ++k) tau[k] = st[k][lane];
     // ---- monochromatic Planck * weight (main.cpp:186-204) for the lane's layers and the surface
-    const double pnum = d.pnum[w], lam5 = d.lam5[w], lkb = d.lkb[w];
+    const double xc = (6.62607e-34 * 299792458.0) / d.lkb[w];  // h*c/(lambda*kB), main.cpp:70-72,191
+    const double sc = d.pnum[w] / d.lam5[w] / 1e9;              // weight*2*h*c^2/lambda^5/1e9, main.cpp:190-191
 #pragma unroll 1
-    for (int k = 0; k <= NH; ++k) st[k][lane] = planck_mono(pnum, lam5, lkb, s.T[p][k]);
+    for (int k = 0; k <= NH; ++k) st[k][lane] = planck_mono_fast(xc, sc, s.T[p][k], s.rT[p][k]);
     double B[NH];
 #pragma unroll
     for (int k = 0; k < NH; ++k) B[k] = st[k][lane];
