@@ -510,3 +510,24 @@ def test_other_angle_counts(pkg, olib, nangle):
         g.step(2), o.step(2)
         _check_fluxes(g, o)
         _check_state(g, o)
+
+
+def test_repwvl_kernel_variants_agree(pkg, olib, monkeypatch):
+    # the lane-per-wavelength reference kernels (library exp, no cube chains, no lane pairs) and the
+    # production lane-pair kernel all against the oracle
+    inp = H.make_inputs(pkg, "repwvl", 5, table="Reduced100")
+    o = H.oracle_ensemble(olib, inp)
+    o.step(3)
+    fo, so = o.get_fluxes(), o.get_state()
+    for expv, cube, pair, chunks in ((0, 0, 0, 0), (0, 1, 1, 1), (1, 0, 0, 2), (1, 1, 0, 4), (1, 1, 1, 3), (1, 0, 1, 0)):
+        monkeypatch.setenv("RCM_EXP_VARIANT", str(expv))
+        monkeypatch.setenv("RCM_CUBE", str(cube))
+        monkeypatch.setenv("RCM_PAIR", str(pair))
+        g = H.gpu_ensemble(pkg, inp)
+        g.set_spectral_chunks(chunks)
+        g.step(3)
+        fg, sg = g.get_fluxes(), g.get_state()
+        for k in fo:
+            assert H.max_abs(fg[k], fo[k]) <= FLUX_TIGHT, (expv, cube, pair, chunks, k)
+        assert H.max_abs(sg["Tlayer"], so["Tlayer"]) <= 1e-9
+        g.close()
