@@ -131,10 +131,12 @@ def main():
         torch.cuda.synchronize()
 
     def gather():
-        ens.pack_state(packed.data_ptr())  # device buffer, on the handle's (= torch's current) stream
+        # The handle runs on its own HIP stream unless given a non-default one (torch's default stream
+        # has handle 0 = "create your own" in the ABI), so order the pack kernel before the collective.
+        ens.pack_state(packed.data_ptr())
+        ens.sync()
         if coll_dev == "cuda":
             return gather_state(packed, ncol_total, world, dist)
-        torch.cuda.synchronize()
         return gather_state(packed.cpu(), ncol_total, world, dist)
 
     ens.step(args.warmup)
