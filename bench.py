@@ -94,7 +94,8 @@ def main():
     assert torch.cuda.is_available(), "bench.py needs the MI355X (no CPU fallback)"
     dev_index = local_rank % torch.cuda.device_count()  # == local_rank on the 8-GPU node
     torch.cuda.set_device(dev_index)
-    if world > 1:
+    use_dist = "RANK" in os.environ  # launched by torch.distributed.run (also with one rank: same code path)
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if args.backend == "nccl":
             dist.init_process_group("nccl", device_id=torch.device("cuda", dev_index))
@@ -126,7 +127,7 @@ def main():
 
     def barrier():
         torch.cuda.synchronize()
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -135,12 +136,12 @@ def main():
         # has handle 0 = "create your own" in the ABI), so order the pack kernel before the collective.
         ens.pack_state(packed.data_ptr())
         ens.sync()
-        if coll_dev == "cuda":
-            return gather_state(packed, ncol_total, world, dist)
-        return gather_state(packed.cpu(), ncol_total, world, dist)
+        if not use_dist:
+            return packed
+        return gather_state(packed if coll_dev == "cuda" else packed.cpu(), ncol_total, world, dist)
 
     ens.step(args.warmup)
-    if world > 1:  # warm the collective too
+    if use_dist:  # warm the collective too
         gather()
     barrier()
     ens.set_rt_timing(True)
@@ -153,7 +154,7 @@ def main():
     ens.set_rt_timing(False)
 
     tmax = torch.tensor([elapsed], dtype=torch.float64, device=coll_dev)
-    if world > 1:
+    if use_dist:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     elapsed = float(tmax.item())
     assert final.shape == (ncol_total, 21) and bool(torch.isfinite(final).all())
@@ -194,7 +195,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"], oe = cpu_baseline(pkg, inp, args.nodes, log)
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
 

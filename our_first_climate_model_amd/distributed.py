@@ -17,10 +17,10 @@ def gather_state(local_packed, ncol_total, world, dist=None):
     `local_packed` is a torch tensor on the rank's device (or CPU for gloo).  Shards are padded to
     ceil(N/world) rows so that one equal-size all-gather does it."""
     import torch
-    if world == 1:
-        return local_packed
     if dist is None:
         import torch.distributed as dist
+    if world == 1 and not (dist.is_available() and dist.is_initialized()):
+        return local_packed
     per = (ncol_total + world - 1) // world
     nlev = local_packed.shape[1]
     send = local_packed
