@@ -36,7 +36,7 @@ struct rcm_ensemble {
   bool have_grid = false, have_columns = false;
   long long step_index = 0;  // the reference's loop variable i (main.cpp:531)
   int user_chunks = 0;
-  int exp_variant = 1, cube = 1, planck_fast = 1, pair = 1;
+  int exp_variant = 1, cube = 1, planck_fast = 1, pair = 1, flat = 1;
   std::vector<double> plevel, player, conv;
   std::vector<void *> allocs;
   Dev d{};
@@ -139,14 +139,28 @@ void choose_chunks(int ncol, int nspec, int user_chunks, int *nchunk_out, int *c
   *nchunk_out = (rows + rows_per_chunk - 1) / rows_per_chunk;
 }
 
+// repwvl with the (column, wavelength) pairs flattened over the lane pairs (k_rt_repwvl_flat): the
+// production path unless the caller pins a chunk count or selects a reference variant.
+bool use_flat(const rcm_ensemble *h) {
+  return h->mode == rcm::MODE_REPWVL && h->flat && h->pair && h->exp_variant == 1 && h->user_chunks == 0 &&
+         h->d.n_wvl >= 8;  // at most 31/8 + 2 = 5 column images per wave
+}
+
 int ensure_partials(rcm_ensemble *h) {
-  choose_chunks(h->ncol, h->d.nspec, h->user_chunks, &h->d.nchunk, &h->d.chunk_len);
+  if (use_flat(h)) {
+    h->d.nchunk = (h->d.n_wvl + 31) / 32 + 1;  // record slots per column, see k_rt_repwvl_flat
+    h->d.chunk_len = 0;
+  } else {
+    choose_chunks(h->ncol, h->d.nspec, h->user_chunks, &h->d.nchunk, &h->d.chunk_len);
+  }
   if (h->partial_buf) {
     HIPCK(hipStreamSynchronize(h->stream));
     HIPCK(hipFree(h->partial_buf));
     h->partial_buf = nullptr;
   }
-  HIPCK(hipMalloc((void **)&h->partial_buf, (size_t)h->ncol * h->d.nchunk * rcm::PSTRIDE * sizeof(double)));
+  const size_t bytes = (size_t)h->ncol * h->d.nchunk * rcm::PSTRIDE * sizeof(double);
+  HIPCK(hipMalloc((void **)&h->partial_buf, bytes));
+  HIPCK(hipMemsetAsync(h->partial_buf, 0, bytes, h->stream));  // slots a column never writes must read as 0
   h->d.partial = h->partial_buf;
   return RCM_OK;
 }
@@ -162,6 +176,15 @@ void launch_rt(rcm_ensemble *h, int blocks) {
     else
 #endif
       hipLaunchKernelGGL((rcm::k_rt_lbl<EXPV, CUBE, 1>), dim3(blocks), dim3(64 * rcm::WPB), 0, h->stream, h->d);
+  } else if (EXPV == 1 && use_flat(h)) {
+    const int maxc = 31 / h->d.n_wvl + 2;
+    const size_t lds = (size_t)rcm::WPB * ((size_t)maxc * sizeof(rcm::RepwvlPairLds) + (size_t)(rcm::NH + 1) * 64 * sizeof(double));
+    const long waves = ((long)h->ncol * h->d.n_wvl + 31) / 32;
+    const auto kern = rcm::k_rt_repwvl_flat<CUBE>;
+    if (lds > 48 * 1024)
+      (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(kern, dim3((unsigned)((waves + rcm::WPB - 1) / rcm::WPB)), dim3(64 * rcm::WPB), lds, h->stream,
+                       h->d, maxc);
   } else if (EXPV == 1 && h->pair) {
     hipLaunchKernelGGL((rcm::k_rt_repwvl_pair<CUBE>), dim3(blocks), dim3(64 * rcm::WPB), 0, h->stream, h->d);
   } else {
@@ -254,6 +277,7 @@ int rcm_create(int ncol, int nlayer, int nangle, int device, void *stream, rcm_e
   if (const char *v = std::getenv("RCM_CUBE")) h->cube = std::atoi(v) ? 1 : 0;
   if (const char *v = std::getenv("RCM_PLANCK_FAST")) h->planck_fast = std::atoi(v) ? 1 : 0;
   if (const char *v = std::getenv("RCM_PAIR")) h->pair = std::atoi(v) ? 1 : 0;
+  if (const char *v = std::getenv("RCM_FLAT")) h->flat = std::atoi(v) ? 1 : 0;
   auto bail = [&](int rc) {
     rcm_destroy(h);
     return rc;
@@ -562,6 +586,7 @@ int rcm_set_spectral_chunks(rcm_ensemble *h, int nchunk) {
 
 int rcm_get_spectral_chunks(rcm_ensemble *h) {
   if (!h || h->mode == rcm::MODE_NONE) return fail(RCM_ERR_STATE, "rcm_get_spectral_chunks: tables not set");
+  if (use_flat(h)) return (h->d.n_wvl + 31) / 32 + 1;
   int nchunk = 0, len = 0;
   choose_chunks(h->ncol, h->d.nspec, h->user_chunks, &nchunk, &len);
   return nchunk;

@@ -535,28 +535,14 @@ struct RepwvlPairLds {
   double rT[2][NH + 1];  // 1/T
   double delT[2][NH], delP[2][NH], numDens[2][NH];
   double vmr[2][RCM_NSPEC_REPWVL][NH];
+  double cloud_tau;
   int it[2][NH], ip[2][NH];
+  int cloud_k[2];  // position of the cloud layer in the lane's ordering (outside [0, NH): none)
 };
 
-template <int CUBE>
-__global__ __launch_bounds__(64 * WPB, RCM_PAIR_LB) void k_rt_repwvl_pair(Dev d) {
-  __shared__ RepwvlPairLds s_col[WPB];
-  __shared__ double s_stage[WPB][NH + 1][64];
-  const int lane = threadIdx.x & 63;
-  const int wib = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  // work item = (chunk, column), column fastest: the waves of a block and neighbouring blocks share
-  // the chunk (its table tile stays in L2); a small ensemble still fills every wave slot
-  const long nitem = (long)d.ncol * d.nchunk;
-  const long item_raw = (long)blockIdx.x * WPB + wib;
-  const bool valid = item_raw < nitem;
-  const long item = valid ? item_raw : nitem - 1;
-  const int chunk = (int)(item / d.ncol);
-  const int col = (int)(item - (long)chunk * d.ncol);
-  const int p = lane & 1;
-  RepwvlPairLds &s = s_col[wib];
-  double(*st)[64] = s_stage[wib];
-
-  // ---- column image: per (parity, position): temperature bracket of read_tau (:229-239)
+// Fills the LDS image of column `col`: per (parity, position) the temperature bracket of read_tau
+// (repwvl_thermal.cpp:229-239), the layer constants, the mixing ratios.  Called by a whole wave.
+__device__ __forceinline__ void repwvl_pair_image(const Dev &d, int col, int lane, RepwvlPairLds &s) {
   if (lane < 2 * (NH + 1)) {
     const int q = lane / (NH + 1), k = lane - q * (NH + 1);
     if (k == NH) {
@@ -579,12 +565,89 @@ __global__ __launch_bounds__(64 * WPB, RCM_PAIR_LB) void k_rt_repwvl_pair(Dev d)
       s.numDens[q][k] = d.numDens[layer];
     }
   }
+  if (lane == 32) {
+    const int cl = d.cloud_layer[col];
+    s.cloud_k[0] = cl;
+    s.cloud_k[1] = NL - 1 - cl;
+    s.cloud_tau = d.cloud_tau[col];
+  }
   for (int i = lane; i < 2 * RCM_NSPEC_REPWVL * NH; i += 64) {
     const int q = i / (RCM_NSPEC_REPWVL * NH), r = i - q * (RCM_NSPEC_REPWVL * NH);
     const int sp = r / NH, k = r - sp * NH;
     const int layer = q ? NL - 1 - k : k;
     s.vmr[q][sp][k] = d.gas[((size_t)col * RCM_NSPEC_REPWVL + sp) * NL + layer];
   }
+}
+
+// One wavelength on a lane pair: optical depths (read_tau :210-246 + cloud), monochromatic Planck
+// (main.cpp:186-204), all angles.  s = the lane's column image, st = the wave's staging column.
+template <int CUBE>
+__device__ __forceinline__ void repwvl_pair_point(const Dev &d, const RepwvlPairLds &s, int p, int w, int lane,
+                                                  double (*st)[64], double (&acc1)[NH + 1], double (&acc2)[NH]) {
+  const size_t ld = d.n_wvl;
+  const int cloud_k = s.cloud_k[p];
+  const double cloud_tau = s.cloud_tau;
+  double tau[NH];
+#pragma unroll 1
+  for (int k = 0; k < NH; ++k) {
+    const int it = s.it[p][k], ip = s.ip[p][k];
+    const double delT = s.delT[p][k], delP = s.delP[p][k];
+    double a = 0.0;
+#pragma unroll
+    for (int sp = 0; sp < RCM_NSPEC_REPWVL; ++sp) {
+      if (!((d.species_mask >> sp) & 1u)) continue;  // vmr == 0 everywhere: the term is +0
+      const double *x0 = d.xsec + (((size_t)it * d.n_species + sp) * d.n_p + ip) * ld + w;
+      const double *x1 = d.xsec + (((size_t)(it + 1) * d.n_species + sp) * d.n_p + ip) * ld + w;
+      const double c0 = x0[0];                   // :235
+      const double cT = x1[0] - c0;              // :236
+      const double cP = x0[ld] - c0;             // :237
+      const double cPT = x1[ld] - cP - cT - c0;  // :238
+      const double xs = c0 + cT * delT + cP * delP + cPT * delT * delP;  // :241
+      a += xs * s.vmr[p][sp][k];                 // :244
+    }
+    a *= s.numDens[p][k];                        // :246
+    if (k == cloud_k) a += cloud_tau;            // main.cpp:266-274
+    st[k][lane] = clamp_tau(a);
+  }
+#pragma unroll
+  for (int k = 0; k < NH; ++k) tau[k] = st[k][lane];
+  const double xc = (6.62607e-34 * 299792458.0) / d.lkb[w];  // h*c/(lambda*kB), main.cpp:70-72,191
+  const double sc = d.pnum[w] / d.lam5[w] / 1e9;              // weight*2*h*c^2/lambda^5/1e9, main.cpp:190-191
+#pragma unroll 1
+  for (int k = 0; k <= NH; ++k) st[k][lane] = planck_mono_fast(xc, sc, s.T[p][k], s.rT[p][k]);
+  double B[NH];
+#pragma unroll
+  for (int k = 0; k < NH; ++k) B[k] = st[k][lane];
+  const double Linit = p ? st[NH][lane] : 0.0;
+
+  const int na = d.nangle;
+  const int N = 2 * na - 1;
+  for (int n = N; CUBE ? 3 * n > N : n >= 1; n -= 2) {
+    const double a2 = -d.ang[(n - 1) >> 1], a1 = a2 * 0x1.71547652b82fep+0;
+    double t[NH];
+#pragma unroll
+    for (int k = 0; k < NH; ++k) t[k] = exp_trans(tau[k], a1, a2);  // main.cpp:209
+    pair_chain<CUBE ? 4 : 0>(d, t, B, Linit, n, acc1, acc2);
+  }
+}
+
+template <int CUBE>
+__global__ __launch_bounds__(64 * WPB, RCM_PAIR_LB) void k_rt_repwvl_pair(Dev d) {
+  __shared__ RepwvlPairLds s_col[WPB];
+  __shared__ double s_stage[WPB][NH + 1][64];
+  const int lane = threadIdx.x & 63;
+  const int wib = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  // work item = (chunk, column), column fastest (see k_rt_lbl_pair)
+  const long nitem = (long)d.ncol * d.nchunk;
+  const long item_raw = (long)blockIdx.x * WPB + wib;
+  const bool valid = item_raw < nitem;
+  const long item = valid ? item_raw : nitem - 1;
+  const int chunk = (int)(item / d.ncol);
+  const int col = (int)(item - (long)chunk * d.ncol);
+  const int p = lane & 1;
+  RepwvlPairLds &s = s_col[wib];
+  double(*st)[64] = s_stage[wib];
+  repwvl_pair_image(d, col, lane, s);
   __syncthreads();
 
   double acc1[NH + 1], acc2[NH];
@@ -592,61 +655,84 @@ __global__ __launch_bounds__(64 * WPB, RCM_PAIR_LB) void k_rt_repwvl_pair(Dev d)
   for (int j = 0; j <= NH; ++j) acc1[j] = 0.0;
 #pragma unroll
   for (int j = 0; j < NH; ++j) acc2[j] = 0.0;
-
   const int w0 = chunk * d.chunk_len;
   const int w1 = min(w0 + d.chunk_len, d.nspec);
-  const int na = d.nangle;
-  const size_t ld = d.n_wvl;
-  const int cloud_layer = d.cloud_layer[col];
-  const double cloud_tau = d.cloud_tau[col];
-  const int cloud_k = p ? NL - 1 - cloud_layer : cloud_layer;
+  for (int w = w0 + (lane >> 1); w < w1; w += 32) repwvl_pair_point<CUBE>(d, s, p, w, lane, st, acc1, acc2);
+  store_pair_partial(d, col, chunk, lane, valid, acc1, acc2);
+}
 
-  for (int w = w0 + (lane >> 1); w < w1; w += 32) {
-    // ---- optical depths of the lane's ten layers: bilinear (p,T) interpolation, :210-246
-    double tau[NH];
-#pragma unroll 1
-    for (int k = 0; k < NH; ++k) {
-      const int it = s.it[p][k], ip = s.ip[p][k];
-      const double delT = s.delT[p][k], delP = s.delP[p][k];
-      double a = 0.0;
+// ---------------------------------------------------------------------------------------------
+// The same, with the (column, wavelength) pairs FLATTENED over the lane pairs: wave i takes the 32
+// consecutive items 32i..32i+31 of the column-major list, whichever columns they belong to (at most
+// 31/n_wvl + 2 of them, each with its own LDS image).  100 wavelengths fill 100/128 of the lane pairs
+// in the chunked kernel, 10 wavelengths 10/32; here every pass is full.  The per-column sums are a
+// segmented reduction through LDS, summed in lane order; a column's partial record goes to slot
+// ceil((first item of the segment - first item of the column)/32), so records never collide and the
+// slots a column never uses stay zero (the buffer is zeroed once).  d.nchunk = number of slots.
+// ---------------------------------------------------------------------------------------------
+template <int CUBE>
+__global__ __launch_bounds__(64 * WPB, RCM_PAIR_LB) void k_rt_repwvl_flat(Dev d, int maxc) {
+  extern __shared__ __align__(16) unsigned char s_dyn[];
+  const int lane = threadIdx.x & 63;
+  const int wib = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const size_t per_wave = (size_t)maxc * sizeof(RepwvlPairLds) + (size_t)(NH + 1) * 64 * sizeof(double);
+  RepwvlPairLds *imgs = reinterpret_cast<RepwvlPairLds *>(s_dyn + wib * per_wave);
+  double(*st)[64] = reinterpret_cast<double(*)[64]>(s_dyn + wib * per_wave + (size_t)maxc * sizeof(RepwvlPairLds));
+  const int p = lane & 1;
+  const long nw = d.n_wvl;
+  const long nflat = (long)d.ncol * nw;
+  const long flat0 = ((long)blockIdx.x * WPB + wib) * 32;
+  int c_first = 0, ncw = 0;  // first column and number of columns this wave touches
+  if (flat0 < nflat) {
+    c_first = (int)(flat0 / nw);
+    ncw = (int)(min(flat0 + 31, nflat - 1) / nw) - c_first + 1;
+  }
+  for (int sl = 0; sl < ncw; ++sl) repwvl_pair_image(d, c_first + sl, lane, imgs[sl]);
+  __syncthreads();
+
+  double acc1[NH + 1], acc2[NH];
 #pragma unroll
-      for (int sp = 0; sp < RCM_NSPEC_REPWVL; ++sp) {
-        if (!((d.species_mask >> sp) & 1u)) continue;  // vmr == 0 everywhere: the term is +0
-        const double *x0 = d.xsec + (((size_t)it * d.n_species + sp) * d.n_p + ip) * ld + w;
-        const double *x1 = d.xsec + (((size_t)(it + 1) * d.n_species + sp) * d.n_p + ip) * ld + w;
-        const double c0 = x0[0];                   // :235
-        const double cT = x1[0] - c0;              // :236
-        const double cP = x0[ld] - c0;             // :237
-        const double cPT = x1[ld] - cP - cT - c0;  // :238
-        const double xs = c0 + cT * delT + cP * delP + cPT * delT * delP;  // :241
-        a += xs * s.vmr[p][sp][k];                 // :244
-      }
-      a *= s.numDens[p][k];                        // :246
-      if (k == cloud_k) a += cloud_tau;            // main.cpp:266-274
-      st[k][lane] = clamp_tau(a);
+  for (int j = 0; j <= NH; ++j) acc1[j] = 0.0;
+#pragma unroll
+  for (int j = 0; j < NH; ++j) acc2[j] = 0.0;
+  const long flat = flat0 + (lane >> 1);
+  if (flat < nflat) {
+    const int col = (int)(flat / nw);
+    repwvl_pair_point<CUBE>(d, imgs[col - c_first], p, (int)(flat - (long)col * nw), lane, st, acc1, acc2);
+  }
+
+  // ---- segmented reduction: round 0 = acc1 (11 values per parity), round 1 = acc2 (10 values)
+#pragma unroll
+  for (int round = 0; round < 2; ++round) {
+    const int nv = round == 0 ? NH + 1 : NH;
+    __syncthreads();  // the staging column is free (previous readers are done)
+    if (round == 0) {
+#pragma unroll
+      for (int j = 0; j <= NH; ++j) st[j][lane] = acc1[j];
+    } else {
+#pragma unroll
+      for (int j = 0; j < NH; ++j) st[j][lane] = acc2[j];
     }
-#pragma unroll
-    for (int k = 0; k < NH; ++k) tau[k] = st[k][lane];
-    // ---- monochromatic Planck * weight (main.cpp:186-204) for the lane's layers and the surface
-    const double xc = (6.62607e-34 * 299792458.0) / d.lkb[w];  // h*c/(lambda*kB), main.cpp:70-72,191
-    const double sc = d.pnum[w] / d.lam5[w] / 1e9;              // weight*2*h*c^2/lambda^5/1e9, main.cpp:190-191
-#pragma unroll 1
-    for (int k = 0; k <= NH; ++k) st[k][lane] = planck_mono_fast(xc, sc, s.T[p][k], s.rT[p][k]);
-    double B[NH];
-#pragma unroll
-    for (int k = 0; k < NH; ++k) B[k] = st[k][lane];
-    const double Linit = p ? st[NH][lane] : 0.0;
-
-    const int N = 2 * na - 1;
-    for (int n = N; CUBE ? 3 * n > N : n >= 1; n -= 2) {
-      const double a2 = -d.ang[(n - 1) >> 1], a1 = a2 * 0x1.71547652b82fep+0;
-      double t[NH];
-#pragma unroll
-      for (int k = 0; k < NH; ++k) t[k] = exp_trans(tau[k], a1, a2);  // main.cpp:209
-      pair_chain<CUBE ? 4 : 0>(d, t, B, Linit, n, acc1, acc2);
+    __syncthreads();
+    if (lane < 2 * nv) {
+      const int q = lane / nv, idx = lane - q * nv;
+      for (int sl = 0; sl < ncw; ++sl) {
+        const long c = c_first + sl;
+        const long seg0 = max(c * nw, flat0), seg1 = min(min((c + 1) * nw, flat0 + 32), nflat);
+        double sum = 0.0;
+        for (long f = seg0; f < seg1; ++f) sum += st[idx][2 * (int)(f - flat0) + q];
+        const long slot = (seg0 - c * nw + 31) / 32;
+        double *oEd = d.partial + ((size_t)c * d.nchunk + slot) * PSTRIDE, *oEu = oEd + NLEV;
+        if (round == 0) {
+          if (q == 0) oEd[idx] = sum;       // E_down[idx], idx = 0..10
+          else oEu[NL - idx] = sum;         // E_up[20-idx]
+        } else {
+          if (q == 0) oEu[idx] = sum;       // E_up[idx], idx = 0..9
+          else oEd[NL - idx] = sum;         // E_down[20-idx]
+        }
+      }
     }
   }
-  store_pair_partial(d, col, chunk, lane, valid, acc1, acc2);
 }
 
 // ---------------------------------------------------------------------------------------------
