@@ -152,7 +152,7 @@ int main(int argc, char **argv) {
     std::fprintf(stderr, "rcm_main: %s has %d levels, need %d\n", o.atm.c_str(), nlev_read, nlevel);
     return 1;
   }
-  const bool lbl = !o.lbl_dir.empty();
+  const bool lbl = !o.lbl_dir.empty() || !o.lbl_cache.empty();
   const int ngas = lbl ? RCM_NSPEC_LBL : RCM_NSPEC_REPWVL;
   std::vector<double> plevel(nlevel), player(nlayer), Tlayer(nlayer), conv(nlayer), vmr9(9 * (size_t)nlayer),
       rel(nlayer), h2o_ref(nlayer);
@@ -201,6 +201,10 @@ int main(int argc, char **argv) {
       rcm_free(cw);
       rcm_free(ct);
     } else {
+      if (o.lbl_dir.empty()) {
+        std::fprintf(stderr, "rcm_main: %s does not exist and no --lbl-dir was given to build it from\n", o.lbl_cache.c_str());
+        return 1;
+      }
       load_lbl(o.lbl_dir, nlayer, wvl, tabs);
       for (int s = 0; s < RCM_NSPEC_LBL; ++s) tp[s] = tabs[s].data();
       if (!o.lbl_cache.empty()) CK(rcm_lbl_cache_write(o.lbl_cache.c_str(), (int)wvl.size(), nlayer, wvl.data(), tp));
