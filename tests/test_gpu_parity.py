@@ -531,3 +531,23 @@ def test_repwvl_kernel_variants_agree(pkg, olib, monkeypatch):
             assert H.max_abs(fg[k], fo[k]) <= FLUX_TIGHT, (expv, cube, pair, chunks, k)
         assert H.max_abs(sg["Tlayer"], so["Tlayer"]) <= 1e-9
         g.close()
+
+
+@pytest.mark.parametrize("table", ["Reduced10", "Reduced20", "Reduced100"])
+def test_flattened_repwvl_kernel_segment_boundaries(pkg, olib, table, monkeypatch):
+    # k_rt_repwvl_flat: a wave's 32 items straddle 2..5 columns; every ensemble size shifts the boundaries
+    for ncol in (1, 2, 3, 5, 33):
+        inp = H.make_inputs(pkg, "repwvl", ncol, table=table)
+        o = H.oracle_ensemble(olib, inp)
+        o.step(2)
+        res = []
+        for flat in ("1", "0"):
+            monkeypatch.setenv("RCM_FLAT", flat)
+            g = H.gpu_ensemble(pkg, inp)
+            g.step(2)
+            _check_fluxes(g, o)
+            _check_state(g, o, 1e-9)
+            res.append(g.get_fluxes())
+            g.close()
+        for k in res[0]:
+            assert H.max_abs(res[0][k], res[1][k]) <= FLUX_TIGHT
