@@ -307,3 +307,36 @@ def test_oracle_lbl_path_against_an_independent_numpy_statement(rcm, olib):
     dE = Ed[:-1] - Ed[1:] + Eu[1:] - Eu[:-1]
     dE[-1] += inp["solar"] + Ed[-1] - Eu[-1]
     np.testing.assert_allclose(f["dE"][1], dE, rtol=0, atol=1e-11)
+
+
+def test_host_abi_error_behaviour(rcm, golden, tmp_path):
+    """No exceptions, no exits: negative codes and a message (where the reference prints and continues,
+    repwvl_thermal.cpp:251-255, or exits, cplkavg.cpp:32-35)."""
+    L = rcm.lib()
+    with pytest.raises(rcm.RcmError) as e:
+        rcm.atm_load(str(tmp_path / "nope.atm"))
+    assert e.value.code == -4 and "cannot open" in str(e.value)
+    short = tmp_path / "short.atm"
+    short.write_text("#\n#\n#\n#\n 1 2 3\n 4 5 6\n")  # only three columns
+    with pytest.raises(rcm.RcmError) as e:
+        rcm.atm_load(str(short))
+    assert e.value.code == -6
+    with pytest.raises(rcm.RcmError) as e:
+        rcm.atm_load(os.path.join(golden, "test.atm"), nlevel_max=10)  # 21 levels do not fit
+    assert e.value.code == -6
+    bad = tmp_path / "bad.rtab"
+    bad.write_bytes(b"NOTATABLE" + b"\0" * 64)
+    with pytest.raises(rcm.RcmError) as e:
+        rcm.read_rtab(str(bad))
+    assert e.value.code == -6
+    trunc = tmp_path / "trunc.rtab"
+    trunc.write_bytes(open(os.path.join(golden, "Reduced10Forcing.rtab"), "rb").read()[:5000])
+    with pytest.raises(rcm.RcmError) as e:
+        rcm.read_rtab(str(trunc))
+    assert e.value.code == -6 and "truncated" in str(e.value)
+    with pytest.raises(rcm.RcmError) as e:
+        rcm.solar_setup(2.0, 0.0)  # cos(SZA) = 0: division by zero in main.cpp:223
+    assert e.value.code == -1
+    assert L.rcm_column_init(21, None, 1.0, 1.0, None, None, None, None, None, None) == -1
+    assert L.rcm_destroy(None) == -1 and L.rcm_step(None, 1) == -1 and L.rcm_sync(None) == -1
+    assert L.rcm_last_error().decode() != ""
