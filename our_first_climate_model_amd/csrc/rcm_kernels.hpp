@@ -37,7 +37,10 @@ constexpr int WPB = 4;       // waves per block = columns per block (one per SIM
 #define RCM_SCHED4 0  // scheduling barrier after every 4th transmission exp
 #endif
 #ifndef RCM_PAIR_LB
-#define RCM_PAIR_LB 2  // waves per SIMD the lane-pair lbl kernel is register-allocated for
+#define RCM_PAIR_LB 3  // waves per SIMD the lane-pair kernels are register-allocated for (<= 168 VGPRs)
+#endif
+#ifndef RCM_SHARED_EMISSION
+#define RCM_SHARED_EMISSION 1  // lane-pair sweeps: form (1-t)*B once per layer and angle, use it in both crossings
 #endif
 #ifndef RCM_PLK_HOIST
 #define RCM_PLK_HOIST 1  // decide the Planck regime once per band (wave vote) and run the loop branch-free
@@ -345,17 +348,33 @@ template <int DEPTH>
 __device__ __forceinline__ void pair_chain(const Dev &d, const double (&t)[NH], const double (&B)[NH],
                                            double Linit, int m, double (&acc1)[NH + 1], double (&acc2)[NH]) {
   const double cw = d.ang[d.nangle + ((m - 1) >> 1)];
+#if RCM_SHARED_EMISSION
+  // A lane crosses each of its layers twice (phase 1 and phase 2) with the same transmission: the
+  // layer's own emission (1-t)*B = alpha*B of main.cpp:307,312 is formed once and both crossings are
+  // L = t*L + e: 5 instead of 6 instructions per layer and angle.
+  double e[NH];
+#pragma unroll
+  for (int k = 0; k < NH; ++k) e[k] = fma(-t[k], B[k], B[k]);
+#endif
   double L = Linit;
   acc1[0] = fma(cw, L, acc1[0]);  // main.cpp:302 in odd lanes (E_up at the surface); even lanes add 0
 #pragma unroll
   for (int k = 0; k < NH; ++k) {
+#if RCM_SHARED_EMISSION
+    L = fma(t[k], L, e[k]);
+#else
     L = fma(t[k], L - B[k], B[k]);
+#endif
     acc1[k + 1] = fma(cw, L, acc1[k + 1]);
   }
   L = pair_swap(L);  // level 10: the down radiance moves to the odd lane, the up radiance to the even lane
 #pragma unroll
   for (int k = NH - 1; k >= 0; --k) {
+#if RCM_SHARED_EMISSION
+    L = fma(t[k], L, e[k]);
+#else
     L = fma(t[k], L - B[k], B[k]);
+#endif
     acc2[k] = fma(cw, L, acc2[k]);
   }
   if constexpr (DEPTH > 0) {
