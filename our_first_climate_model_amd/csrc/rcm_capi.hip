@@ -318,12 +318,13 @@ int rcm_create(int ncol, int nlayer, int nangle, int device, void *stream, rcm_e
   if (rc) return bail(rc);
   d.ip = h->d_ip, d.delP = h->d_delP, d.numDens = h->d_numDens;
   // angles: mu_i = dmu/2 + dmu*i (main.cpp:356,482); weight 2*pi*mu*dmu (main.cpp:302,308,313)
-  std::vector<double> ang(2 * (size_t)nangle);
+  std::vector<double> ang(2 * (size_t)nangle + 1, 0.0);
   const double dmu = 1.0 / (double)nangle;
   for (int i = 0; i < nangle; ++i) {
     const double mu = dmu / 2.0 + dmu * (double)i;
     ang[i] = 1.0 / mu;
     ang[nangle + i] = 2 * M_PI * mu * dmu;
+    ang[2 * nangle] += ang[nangle + i];  // sum of the quadrature weights (= pi up to rounding)
   }
   if ((rc = dev_upload(h, (double **)&d.ang, ang.data(), ang.size()))) return bail(rc);
   hipError_t me = hipMemsetAsync(d.time_h, 0, ncol * sizeof(float), h->stream);

@@ -68,7 +68,7 @@ struct Dev {
   double *resid;  // equilibrium residual per column: max_l |change of the ADJUSTED profile| between the
                   // last two iterations [K] (1e300 until two iterations have run)
   double *Tprev;  // adjusted profile of the previous iteration
-  const double *player, *conv, *ang;  // ang = [inv_mu[nangle], cw[nangle]]
+  const double *player, *conv, *ang;  // ang = [inv_mu[nangle], cw[nangle], sum of cw]
   double *T, *Ttau, *Tsfc, *dt, *gas, *E_down, *E_up, *dE, *partial;
   const double *rel_hum;
   float *time_h;
@@ -356,8 +356,7 @@ __device__ __forceinline__ void pair_chain(const Dev &d, const double (&t)[NH], 
 #pragma unroll
   for (int k = 0; k < NH; ++k) e[k] = fma(-t[k], B[k], B[k]);
 #endif
-  double L = Linit;
-  acc1[0] = fma(cw, L, acc1[0]);  // main.cpp:302 in odd lanes (E_up at the surface); even lanes add 0
+  double L = Linit;  // its own flux contribution (main.cpp:302) is added once per band by the caller
 #pragma unroll
   for (int k = 0; k < NH; ++k) {
 #if RCM_SHARED_EMISSION
@@ -528,6 +527,7 @@ __global__ __launch_bounds__(64 * WPB, RCM_PAIR_LB) void k_rt_lbl_pair(Dev d) {
 #pragma unroll
     for (int k = 0; k < NH; ++k) B[k] = st[k][lane];
     const double Linit = p ? st[NH][lane] : 0.0;  // main.cpp:300-301
+    acc1[0] = fma(d.ang[2 * na], Linit, acc1[0]);  // main.cpp:302 for all angles at once: sum_i 2*pi*mu_i*dmu * L_up
 
     // ---- angles (main.cpp:297): odd n = 2i+1; with CUBE only 3n > 2*nangle-1 needs exps
     const int N = 2 * na - 1;
@@ -640,6 +640,7 @@ __device__ __forceinline__ void repwvl_pair_point(const Dev &d, const RepwvlPair
   const double Linit = p ? st[NH][lane] : 0.0;
 
   const int na = d.nangle;
+  acc1[0] = fma(d.ang[2 * na], Linit, acc1[0]);  // main.cpp:302 for all angles at once
   const int N = 2 * na - 1;
   for (int n = N; CUBE ? 3 * n > N : n >= 1; n -= 2) {
     const double a2 = -d.ang[(n - 1) >> 1], a1 = a2 * 0x1.71547652b82fep+0;
