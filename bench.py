@@ -200,7 +200,7 @@ def main():
                          "launches": rt_n,
                          "note": "numerator = 808 B per (column, band), as if every column streamed the 5 species "
                                  "tables itself (SURVEY 8d); the tables are shared, real HBM traffic is ~1% of "
-                                 "that and the kernel is fp64-VALU-issue bound (96% VALU busy, profiles/README.md)"},
+                                 "that and the kernel is fp64-VALU-issue bound (94% VALU busy, profiles/README.md)"},
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"], oe = cpu_baseline(pkg, inp, args.nodes, log)
