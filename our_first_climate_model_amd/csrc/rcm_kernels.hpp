@@ -386,6 +386,34 @@ __device__ __forceinline__ void pair_chain(const Dev &d, const double (&t)[NH], 
   }
 }
 
+// All angles of one spectral point on a lane pair (main.cpp:297).  mu_i = (2i+1)/(2*nangle): with odd
+// angle numbers n = 2i+1 <= N = 2*nangle-1 the transmission is t_n = exp(-tau*2*nangle/n), so
+// t_{n/3} = t_n^3: with CUBE only the "roots" n > N/3 need their own evaluation (pair_chain does the rest).
+template <int CUBE>
+__device__ __forceinline__ void pair_all_angles(const Dev &d, const double (&tau)[NH], const double (&B)[NH],
+                                                double Linit, double (&acc1)[NH + 1], double (&acc2)[NH]) {
+  const int na = d.nangle;
+  const int N = 2 * na - 1;
+  acc1[0] = fma(d.ang[2 * na], Linit, acc1[0]);  // main.cpp:302 for all angles at once: sum_i 2*pi*mu_i*dmu * L_up
+  if constexpr (!CUBE) {
+    for (int n = N; n >= 1; n -= 2) {
+      const double a2 = -d.ang[(n - 1) >> 1], a1 = a2 * 0x1.71547652b82fep+0;
+      double t[NH];
+#pragma unroll
+      for (int k = 0; k < NH; ++k) t[k] = exp_trans(tau[k], a1, a2);  // main.cpp:209
+      pair_chain<0>(d, t, B, Linit, n, acc1, acc2);
+    }
+  } else {
+    for (int n = N; 3 * n > N; n -= 2) {
+      const double a2 = -d.ang[(n - 1) >> 1], a1 = a2 * 0x1.71547652b82fep+0;
+      double t[NH];
+#pragma unroll
+      for (int k = 0; k < NH; ++k) t[k] = exp_trans(tau[k], a1, a2);  // main.cpp:209
+      pair_chain<4>(d, t, B, Linit, n, acc1, acc2);
+    }
+  }
+}
+
 // Reduce the accumulators over the 32 lanes of each parity (offsets 32..2) and store the record.
 // even lane: acc1[j] = E_down[j] (j = 0..10), acc2[k] = E_up[k] (k = 0..9)
 // odd lane:  acc1[j] = E_up[20-j],           acc2[k] = E_down[20-k]
@@ -474,7 +502,6 @@ __global__ __launch_bounds__(64 * WPB, RCM_PAIR_LB) void k_rt_lbl_pair(Dev d) {
 
   const long b0 = (long)chunk * d.chunk_len;
   const long b1 = min(b0 + (long)d.chunk_len, (long)d.nspec);
-  const int na = d.nangle;
   // the lane's first table row and the row step: layers 0,1,.. (even) or 19,18,.. (odd)
   const double *row0 = d.lbl_tab + (size_t)(p ? NL - 1 : 0) * d.lbl_ld;
   const long rstep = p ? -d.lbl_ld : d.lbl_ld;
@@ -527,17 +554,7 @@ __global__ __launch_bounds__(64 * WPB, RCM_PAIR_LB) void k_rt_lbl_pair(Dev d) {
 #pragma unroll
     for (int k = 0; k < NH; ++k) B[k] = st[k][lane];
     const double Linit = p ? st[NH][lane] : 0.0;  // main.cpp:300-301
-    acc1[0] = fma(d.ang[2 * na], Linit, acc1[0]);  // main.cpp:302 for all angles at once: sum_i 2*pi*mu_i*dmu * L_up
-
-    // ---- angles (main.cpp:297): odd n = 2i+1; with CUBE only 3n > 2*nangle-1 needs exps
-    const int N = 2 * na - 1;
-    for (int n = N; CUBE ? 3 * n > N : n >= 1; n -= 2) {
-      const double a2 = -d.ang[(n - 1) >> 1], a1 = a2 * 0x1.71547652b82fep+0;
-      double t[NH];
-#pragma unroll
-      for (int k = 0; k < NH; ++k) t[k] = exp_trans(tau[k], a1, a2);  // main.cpp:209
-      pair_chain<CUBE ? 4 : 0>(d, t, B, Linit, n, acc1, acc2);
-    }
+    pair_all_angles<CUBE>(d, tau, B, Linit, acc1, acc2);
   }
 
   store_pair_partial(d, col, chunk, lane, valid, acc1, acc2);
@@ -639,16 +656,7 @@ __device__ __forceinline__ void repwvl_pair_point(const Dev &d, const RepwvlPair
   for (int k = 0; k < NH; ++k) B[k] = st[k][lane];
   const double Linit = p ? st[NH][lane] : 0.0;
 
-  const int na = d.nangle;
-  acc1[0] = fma(d.ang[2 * na], Linit, acc1[0]);  // main.cpp:302 for all angles at once
-  const int N = 2 * na - 1;
-  for (int n = N; CUBE ? 3 * n > N : n >= 1; n -= 2) {
-    const double a2 = -d.ang[(n - 1) >> 1], a1 = a2 * 0x1.71547652b82fep+0;
-    double t[NH];
-#pragma unroll
-    for (int k = 0; k < NH; ++k) t[k] = exp_trans(tau[k], a1, a2);  // main.cpp:209
-    pair_chain<CUBE ? 4 : 0>(d, t, B, Linit, n, acc1, acc2);
-  }
+  pair_all_angles<CUBE>(d, tau, B, Linit, acc1, acc2);
 }
 
 template <int CUBE>
