@@ -14,6 +14,10 @@
 #include "rcm_internal.hpp"
 #include "rcm_kernels.hpp"
 
+#ifndef RCM_GEN15
+#define RCM_GEN15 1  // root pairs 3m / 5m from one exponential (0: every root its own)
+#endif
+
 // =============================================================================================
 // Host side: the handle and the C ABI.
 // =============================================================================================
@@ -325,6 +329,31 @@ int rcm_create(int ncol, int nlayer, int nangle, int device, void *stream, rcm_e
     ang[i] = 1.0 / mu;
     ang[nangle + i] = 2 * M_PI * mu * dmu;
     ang[2 * nangle] += ang[nangle + i];  // sum of the quadrature weights (= pi up to rounding)
+  }
+  // Root schedule of the lane-pair kernels (pair_all_angles): odd angle numbers n = 2i+1 with 3n > N need
+  // an exponential of their own (the others follow by cubing); two roots 3m and 5m share the exponential
+  // of the fictitious angle number 15m.  Entry = {a1 = -log2(e)/mu, bits of 4*n + mode}.
+  {
+    const int N = 2 * nangle - 1;
+    const double log2e = 0x1.71547652b82fep+0;
+    std::vector<char> used((size_t)N + 1, 0);
+    auto is_root = [&](int n) { return n >= 1 && n <= N && (n & 1) && 3 * n > N; };
+    auto push = [&](double a1, int n, int mode) {
+      const long long code = 4LL * n + mode;
+      double bits;
+      std::memcpy(&bits, &code, sizeof bits);
+      ang.push_back(a1), ang.push_back(bits);
+    };
+    d.nsched = 0;
+    for (int m = N / 5; RCM_GEN15 && m >= 1; --m) {
+      if (!(m & 1) || !is_root(3 * m) || !is_root(5 * m) || used[3 * m] || used[5 * m]) continue;
+      used[3 * m] = used[5 * m] = 1;
+      push(-(2.0 * nangle) / (15.0 * m) * log2e, 3 * m, 1);
+      push(0.0, 5 * m, 2);
+      d.nsched += 2;
+    }
+    for (int n = N; n >= 1; n -= 2)
+      if (is_root(n) && !used[n]) push(-ang[(n - 1) >> 1] * log2e, n, 0), ++d.nsched;
   }
   if ((rc = dev_upload(h, (double **)&d.ang, ang.data(), ang.size()))) return bail(rc);
   hipError_t me = hipMemsetAsync(d.time_h, 0, ncol * sizeof(float), h->stream);

@@ -227,20 +227,23 @@ __device__ __forceinline__ double exp_pos(double x) {
   return __builtin_amdgcn_ldexp(q, __double2loint(z));
 }
 
-// The fast formula itself, preconditions established by the caller.
-__device__ __forceinline__ double cplkavg_fast_eval(double v0, double v1, double pc) {
-  const double hh = v1 - v0;
-  const double xm = 0.5 * (v0 + v1);
+// The fast formula itself, preconditions established by the caller: xm = argument at the band centre,
+// hh = its width.
+__device__ __forceinline__ double cplkavg_fast_mid(double xm, double hh, double pc) {
   const double d = exp_pos(xm) - 1.0;
   double g = __builtin_amdgcn_rcp(d);  // ~2^-26 relative; two Newton steps reach full precision
   g = fma(fma(-d, g, 1.0), g, g);
   g = fma(fma(-d, g, 1.0), g, g);
-  const double g1 = -g * (1.0 + g);          // dg/dx
+  const double g1 = fma(-g, g, -g);          // dg/dx = -g(1+g)
   const double g2 = -g1 * fma(2.0, g, 1.0);  // d2g/dx2
   const double x2 = xm * xm, x3 = x2 * xm;
   const double f = x3 * g;
   const double f2 = fma(x3, g2, fma(6.0 * x2, g1, 6.0 * xm * g));
   return pc * (hh * fma(hh * hh * (1.0 / 24.0), f2, f));
+}
+
+__device__ __forceinline__ double cplkavg_fast_eval(double v0, double v1, double pc) {
+  return cplkavg_fast_mid(0.5 * (v0 + v1), v1 - v0, pc);
 }
 
 __device__ __forceinline__ bool cplkavg_fast(double c2lo, double c2hi, double t, double rT,

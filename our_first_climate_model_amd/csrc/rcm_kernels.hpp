@@ -68,7 +68,8 @@ struct Dev {
   double *resid;  // equilibrium residual per column: max_l |change of the ADJUSTED profile| between the
                   // last two iterations [K] (1e300 until two iterations have run)
   double *Tprev;  // adjusted profile of the previous iteration
-  const double *player, *conv, *ang;  // ang = [inv_mu[nangle], cw[nangle], sum of cw]
+  const double *player, *conv, *ang;  // ang = [inv_mu[nangle], cw[nangle], sum of cw, schedule {a1, code}[nsched]]
+  int nsched;                         // entries of the root schedule (pair_all_angles)
   double *T, *Ttau, *Tsfc, *dt, *gas, *E_down, *E_up, *dE, *partial;
   const double *rel_hum;
   float *time_h;
@@ -388,15 +389,21 @@ __device__ __forceinline__ void pair_chain(const Dev &d, const double (&t)[NH], 
 
 // All angles of one spectral point on a lane pair (main.cpp:297).  mu_i = (2i+1)/(2*nangle): with odd
 // angle numbers n = 2i+1 <= N = 2*nangle-1 the transmission is t_n = exp(-tau*2*nangle/n), so
-// t_{n/3} = t_n^3: with CUBE only the "roots" n > N/3 need their own evaluation (pair_chain does the rest).
+//   * t_{n/3} = t_n^3: with CUBE only the "roots" n > N/3 need their own evaluation (pair_chain does the rest);
+//   * two roots 3m and 5m can share ONE exponential u = exp(-tau*2*nangle/(15m)) at a fictitious angle:
+//     t_5m = u^3, t_3m = u^5 (30 angles: 21/35, 27/45, 33/55).
+// The host lays this out as a schedule behind the angle table (rcm_create): entries {a1, code} with
+// a1 = -log2(e)/mu of the exponential to evaluate and code = 4*n + mode, mode 0: plain root n, 1: a1 is the
+// generator of (n = 3m, 5m), u^3 is parked in the lane's LDS column st (free during the angle loop),
+// 2: n = 5m, transmissions come back from st.
 template <int CUBE>
 __device__ __forceinline__ void pair_all_angles(const Dev &d, const double (&tau)[NH], const double (&B)[NH],
-                                                double Linit, double (&acc1)[NH + 1], double (&acc2)[NH]) {
+                                                double Linit, double (*st)[64], int lane, double (&acc1)[NH + 1],
+                                                double (&acc2)[NH]) {
   const int na = d.nangle;
-  const int N = 2 * na - 1;
   acc1[0] = fma(d.ang[2 * na], Linit, acc1[0]);  // main.cpp:302 for all angles at once: sum_i 2*pi*mu_i*dmu * L_up
   if constexpr (!CUBE) {
-    for (int n = N; n >= 1; n -= 2) {
+    for (int n = 2 * na - 1; n >= 1; n -= 2) {
       const double a2 = -d.ang[(n - 1) >> 1], a1 = a2 * 0x1.71547652b82fep+0;
       double t[NH];
 #pragma unroll
@@ -404,12 +411,27 @@ __device__ __forceinline__ void pair_all_angles(const Dev &d, const double (&tau
       pair_chain<0>(d, t, B, Linit, n, acc1, acc2);
     }
   } else {
-    for (int n = N; 3 * n > N; n -= 2) {
-      const double a2 = -d.ang[(n - 1) >> 1], a1 = a2 * 0x1.71547652b82fep+0;
+    const double *sched = d.ang + 2 * na + 1;
+    for (int s = 0; s < d.nsched; ++s) {
+      const double a1 = sched[2 * s], a2 = a1 * 0x1.62e42fefa39efp-1;
+      const int code = (int)__double_as_longlong(sched[2 * s + 1]);
       double t[NH];
+      if ((code & 3) == 2) {
 #pragma unroll
-      for (int k = 0; k < NH; ++k) t[k] = exp_trans(tau[k], a1, a2);  // main.cpp:209
-      pair_chain<4>(d, t, B, Linit, n, acc1, acc2);
+        for (int k = 0; k < NH; ++k) t[k] = st[k][lane];
+      } else {
+#pragma unroll
+        for (int k = 0; k < NH; ++k) t[k] = exp_trans(tau[k], a1, a2);  // main.cpp:209
+        if (code & 1) {
+#pragma unroll
+          for (int k = 0; k < NH; ++k) {
+            const double u2 = t[k] * t[k], u3 = u2 * t[k];
+            st[k][lane] = u3;
+            t[k] = u3 * u2;
+          }
+        }
+      }
+      pair_chain<4>(d, t, B, Linit, code >> 2, acc1, acc2);
     }
   }
 }
@@ -536,10 +558,11 @@ __global__ __launch_bounds__(64 * WPB, RCM_PAIR_LB) void k_rt_lbl_pair(Dev d) {
     const bool lane_fast = narrow && (c2hi - c2lo) * rTmin < 0.999 * kHhFast && c2hi * rTmin < 699.0 &&
                            c2lo * rTmax > 1e-15;
     if (RCM_PLK_HOIST && __all(lane_fast)) {
+      const double c2mid = 0.5 * (c2lo + c2hi), dc2 = c2hi - c2lo;
 #pragma unroll RCM_PAIR_PLK_UNROLL
       for (int k = 0; k <= NH; ++k) {
         const double t = s.T[p][k], rT = s.rT[p][k];
-        st[k][lane] = cplkavg_fast_eval(div_by_t(c2lo, t, rT), div_by_t(c2hi, t, rT), s.pc[p][k]);
+        st[k][lane] = cplkavg_fast_mid(div_by_t(c2mid, t, rT), dc2 * rT, s.pc[p][k]);
       }
     } else {
 #pragma unroll 1
@@ -554,7 +577,7 @@ __global__ __launch_bounds__(64 * WPB, RCM_PAIR_LB) void k_rt_lbl_pair(Dev d) {
 #pragma unroll
     for (int k = 0; k < NH; ++k) B[k] = st[k][lane];
     const double Linit = p ? st[NH][lane] : 0.0;  // main.cpp:300-301
-    pair_all_angles<CUBE>(d, tau, B, Linit, acc1, acc2);
+    pair_all_angles<CUBE>(d, tau, B, Linit, st, lane, acc1, acc2);
   }
 
   store_pair_partial(d, col, chunk, lane, valid, acc1, acc2);
@@ -656,7 +679,7 @@ __device__ __forceinline__ void repwvl_pair_point(const Dev &d, const RepwvlPair
   for (int k = 0; k < NH; ++k) B[k] = st[k][lane];
   const double Linit = p ? st[NH][lane] : 0.0;
 
-  pair_all_angles<CUBE>(d, tau, B, Linit, acc1, acc2);
+  pair_all_angles<CUBE>(d, tau, B, Linit, st, lane, acc1, acc2);
 }
 
 template <int CUBE>
