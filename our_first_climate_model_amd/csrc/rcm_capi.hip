@@ -549,6 +549,8 @@ int rcm_set_lbl_tables(rcm_ensemble *h, int n_nodes, const double *wvl,
   Dev &d = h->d;
   const long nband = n_nodes - 1;
   const long ld = (nband + 63) / 64 * 64;
+  if ((unsigned long long)RCM_NSPEC_LBL * NL * ld * sizeof(double) >= (1ull << 32))
+    return fail(RCM_ERR_ARG, "rcm_set_lbl_tables: the five tables must stay below 4 GiB (32-bit offsets in the kernel)");
   double *tab = nullptr, *stage = nullptr;
   if (int rc = dev_alloc(h, &tab, (size_t)RCM_NSPEC_LBL * NL * ld)) return rc;
   HIPCK(hipMalloc((void **)&stage, (size_t)n_nodes * NL * sizeof(double)));
@@ -567,6 +569,9 @@ int rcm_set_lbl_tables(rcm_ensemble *h, int n_nodes, const double *wvl,
   (void)hipFree(stage);
   int rc = 0;
   rc = rc ? rc : dev_upload(h, (double **)&d.lbl_wvl, wvl, (size_t)n_nodes);
+  std::vector<double> wnum((size_t)n_nodes);
+  for (int i = 0; i < n_nodes; ++i) wnum[i] = 1.0E7 / wvl[i];  // cplkavg.cpp:141-142
+  rc = rc ? rc : dev_upload(h, (double **)&d.lbl_wnum, wnum.data(), wnum.size());
   rc = rc ? rc : dev_upload(h, (double **)&d.h2o_ref, h2o_ref, (size_t)NL);
   if (rc) return rc;
   d.lbl_tab = tab;

@@ -75,6 +75,7 @@ struct Dev {
   float *time_h;
   // lbl: tab[s][l][ld] (band fastest), wvl[n_nodes], h2o_ref[NL]
   const double *lbl_tab, *lbl_wvl, *h2o_ref;
+  const double *lbl_wnum;  // 1.0E7 / lbl_wvl[i] (cplkavg.cpp:141-142), formed once on the host
   long lbl_ld;
   // repwvl: xsec[t][s][p][w] (wavelength fastest)
   const double *xsec, *t_ref, *t_pert, *delP, *numDens, *pnum, *lam5, *lkb;
@@ -467,6 +468,7 @@ struct PairLds {
   double pc[2][NH + 1];   // sigdpi * T^4 * conc     (cplkavg.cpp:181)
   double rT[2][NH + 1];   // 1/T
   double gas[2][RCM_NSPEC_LBL][NH];
+  double cloud[2][NH];    // grey cloud optical depth of the layer (main.cpp:266-274), 0 elsewhere
 };
 
 template <int CUBE>
@@ -504,6 +506,10 @@ __global__ __launch_bounds__(64 * WPB, RCM_PAIR_LB) void k_rt_lbl_pair(Dev d) {
     const int layer = q ? NL - 1 - k : k;
     s.gas[q][sp][k] = d.gas[((size_t)col * RCM_NSPEC_LBL + sp) * NL + layer];
   }
+  if (lane < 2 * NH) {
+    const int q = lane / NH, k = lane - q * NH;
+    s.cloud[q][k] = ((q ? NL - 1 - k : k) == d.cloud_layer[col]) ? d.cloud_tau[col] : 0.0;
+  }
   __syncthreads();
 
   // reciprocal of the column's coldest / warmest temperature (for the once-per-band Planck regime test)
@@ -524,34 +530,38 @@ __global__ __launch_bounds__(64 * WPB, RCM_PAIR_LB) void k_rt_lbl_pair(Dev d) {
 
   const long b0 = (long)chunk * d.chunk_len;
   const long b1 = min(b0 + (long)d.chunk_len, (long)d.nspec);
-  // the lane's first table row and the row step: layers 0,1,.. (even) or 19,18,.. (odd)
-  const double *row0 = d.lbl_tab + (size_t)(p ? NL - 1 : 0) * d.lbl_ld;
-  const long rstep = p ? -d.lbl_ld : d.lbl_ld;
-  const int cloud_layer = d.cloud_layer[col];
-  const double cloud_tau = d.cloud_tau[col];
-  const int cloud_k = p ? NL - 1 - cloud_layer : cloud_layer;  // position of the cloud layer, if in [0, NH)
+  // Table addressing: one scalar base per species + a 32-bit byte offset per lane (the five tables are
+  // < 4 GiB together, rcm_set_lbl_tables checks), so a load costs no vector address arithmetic.
+  // The lane's first row and the row step: layers 0,1,.. (even) or 19,18,.. (odd).
+  const char *sbase[RCM_NSPEC_LBL];
+#pragma unroll
+  for (int sp = 0; sp < RCM_NSPEC_LBL; ++sp) sbase[sp] = (const char *)(d.lbl_tab + (size_t)sp * NL * d.lbl_ld);
+  const unsigned row0 = (unsigned)((p ? NL - 1 : 0) * d.lbl_ld) * 8u;
+  const unsigned rstep = (unsigned)d.lbl_ld * 8u * (p ? -1 : 1);
 
   for (long b = b0 + (lane >> 1); b < b1; b += 32) {  // main.cpp:329: 32 bands per wave pass
     // ---- optical depths of the lane's ten layers (lbl composition + cloud, main.cpp:266-274)
     double tau[NH];
     {
-      const double *rp = row0 + b;
+      unsigned off = row0 + (unsigned)b * 8u;
 #pragma unroll 2
-      for (int k = 0; k < NH; ++k, rp += rstep) {  // rolled: bounds the loads (and VGPRs) in flight
+      for (int k = 0; k < NH; ++k, off += rstep) {  // rolled: bounds the loads (and VGPRs) in flight
         double a = 0.0;
 #pragma unroll
-        for (int sp = 0; sp < RCM_NSPEC_LBL; ++sp) a = fma(s.gas[p][sp][k], rp[(size_t)sp * NL * d.lbl_ld], a);
-        if (k == cloud_k) a += cloud_tau;
-        st[k][lane] = clamp_tau(a);
+        for (int sp = 0; sp < RCM_NSPEC_LBL; ++sp)
+          a = fma(s.gas[p][sp][k], *(const double *)(sbase[sp] + off), a);
+        st[k][lane] = clamp_tau(a + s.cloud[p][k]);  // + 0.0 leaves the other layers as they are
       }
 #pragma unroll
       for (int k = 0; k < NH; ++k) tau[k] = st[k][lane];
     }
     // ---- band Planck source of the lane's ten layers and of the surface (cplkavg.cpp:124-243)
-    const double wnumhi = 1.0E7 / d.lbl_wvl[b];      // cplkavg.cpp:141
-    const double wnumlo = 1.0E7 / d.lbl_wvl[b + 1];  // cplkavg.cpp:142
+    const double wnumhi = d.lbl_wnum[b];      // cplkavg.cpp:141
+    const double wnumlo = d.lbl_wnum[b + 1];  // cplkavg.cpp:142
     const double c2lo = 1.438786 * wnumlo, c2hi = 1.438786 * wnumhi;  // cplkavg.cpp:152-153
-    const bool narrow = (wnumhi - wnumlo) / wnumhi < 1.e-2;           // cplkavg.cpp:155
+    // gate of the fast path only (the slow path repeats cplkavg.cpp:155 itself): a shade inside
+    // (wnumhi - wnumlo) / wnumhi < 1.e-2, without the division
+    const bool narrow = wnumhi - wnumlo < 0.999e-2 * wnumhi;
     // Is every one of the column's 21 temperatures in the narrow-band regime for this lane's band
     // (hh = (c2hi-c2lo)/T < kHhFast, eps < v < 700)?  Decided once per band from Tmin/Tmax with a 0.1 %
     // margin; when the whole wave agrees the Planck loop runs branch-free.
