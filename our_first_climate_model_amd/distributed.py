@@ -30,3 +30,31 @@ def gather_state(local_packed, ncol_total, world, dist=None):
     recv = torch.empty((world * per, nlev), dtype=send.dtype, device=send.device)
     dist.all_gather_into_tensor(recv, send.contiguous())
     return recv[:ncol_total]
+
+
+def run_to_equilibrium(ens, tol_K, max_steps, check_every=10, dist=None):
+    """Steps every rank's shard `check_every` iterations at a time until the WORST column of the whole
+    ensemble has a residual <= tol_K (rcm_get_residual: change of the adjusted profile per iteration)
+    or max_steps have run: one all-reduce(max) of one double per check, so all ranks stop after the
+    same number of iterations and the gathered state is one consistent iteration of the ensemble
+    (BASELINE configs[4]).  Returns (steps_done, worst_residual_K).
+    `ens` needs step(n) and get_residual() (our_first_climate_model_amd.Ensemble)."""
+    import torch
+    if dist is None:
+        import torch.distributed as dist
+    multi = dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+    done, worst = 0, float("inf")
+    while done < max_steps:
+        n = min(check_every, max_steps - done)
+        ens.step(n)
+        done += n
+        r = ens.get_residual()
+        worst = float(np.max(r)) if len(r) else 0.0  # an empty shard never holds the others back
+        if multi:
+            backend = dist.get_backend()
+            t = torch.tensor([worst], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            worst = float(t.item())
+        if worst <= tol_K:
+            break
+    return done, worst

@@ -90,3 +90,52 @@ def test_sweep_windows_concatenate_to_the_full_sweep(rcm):
         np.testing.assert_array_equal(np.concatenate([getattr(p, k) for p in parts]), getattr(full, k))
     s0 = full.shard(1, 2)
     np.testing.assert_array_equal(s0.co2_factor, parts[1].co2_factor)
+
+
+def _rank_equilibrium(rank, world, port, ncol_total, q):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import torch.distributed as dist
+    import helpers as H
+    import oracle_lib as ol
+    import our_first_climate_model_amd as pkg
+    from our_first_climate_model_amd.distributed import run_to_equilibrium, shard_bounds
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+    try:
+        lo, hi = shard_bounds(ncol_total, rank, world)
+        atm_cols, _ = pkg.atm_load(os.path.join(ROOT, "tests", "golden", "test.atm"))
+        spec = pkg.perturbation_sweep(hi - lo, perturb_rh=True, perturb_ts=True, first=lo, total=ncol_total)
+        cols = pkg.build_columns(atm_cols, spec, "repwvl")
+        inp = dict(mode="repwvl", ncol=hi - lo, cols=cols, solar=pkg.default_solar()["solar_irr"],
+                   table=ol.read_rtab(os.path.join(ROOT, "tests", "golden", "Reduced10Forcing.rtab")))
+        e = H.oracle_ensemble(ol.load(), inp, threads=1)
+        done, worst = run_to_equilibrium(e, 0.5, 60, check_every=5, dist=dist)
+        q.put((rank, done, worst, float(e.get_residual().max())))
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_ranks_stop_on_the_global_residual(rcm, olib):
+    """Both ranks run until the worst column of the WHOLE ensemble is below the tolerance: same step
+    count on both, equal to the one-rank run of the full ensemble."""
+    import torch.multiprocessing as mp
+    import helpers as H
+    ncol_total = 6
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_rank_equilibrium, args=(r, 2, port, ncol_total, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = sorted(q.get(timeout=240) for _ in range(2))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    inp = H.make_inputs(rcm, "repwvl", ncol_total, table="Reduced10")
+    e = H.oracle_ensemble(olib, inp, threads=2)
+    done1, worst1 = e.run_to_equilibrium(0.5, 60, check_every=5)
+    assert 5 <= done1 < 60  # the criterion, not the step cap, ended the run
+    assert [g[1] for g in got] == [done1, done1]
+    assert got[0][2] == got[1][2] == worst1
+    assert max(g[3] for g in got) == worst1  # the global value is the larger of the two local ones
