@@ -496,6 +496,8 @@ int rcm_set_repwvl_tables(rcm_ensemble *h, int n_tpert, int n_species, int n_wvl
   if (n_species != RCM_NSPEC_REPWVL) return fail(RCM_ERR_ARG, "rcm_set_repwvl_tables: n_species must be 9");
   if (n_tpert < 2 || n_p < 2 || n_wvl < 1) return fail(RCM_ERR_ARG, "rcm_set_repwvl_tables: bad dimensions");
   if (h->mode != rcm::MODE_NONE) return fail(RCM_ERR_STATE, "rcm_set_repwvl_tables: tables already set");
+  if ((unsigned long long)n_tpert * n_species * n_p * n_wvl * sizeof(double) >= (1ull << 32))
+    return fail(RCM_ERR_ARG, "rcm_set_repwvl_tables: the table must stay below 4 GiB (32-bit offsets in the kernel)");
   if (int rc = use_device(h)) return rc;
   Dev &d = h->d;
   // re-lay out [t][s][w][p] -> [t][s][p][w] so that a wave's 64 wavelengths are contiguous
@@ -507,7 +509,7 @@ int rcm_set_repwvl_tables(rcm_ensemble *h, int n_tpert, int n_species, int n_wvl
           xt[(((size_t)t * n_species + s) * n_p + p) * n_wvl + w] =
               xsec[(((size_t)t * n_species + s) * n_wvl + w) * n_p + p];
   // per-wavelength Planck constants in the reference's operation order (main.cpp:188-191)
-  std::vector<double> pnum(n_wvl), lam5(n_wvl), lkb(n_wvl);
+  std::vector<double> pnum(n_wvl), lam5(n_wvl), lkb(n_wvl), rw_xc(n_wvl), rw_sc(n_wvl);
   const double hP = 6.62607e-34, cL = 299792458, kB = 1.380649e-23;  // main.cpp:70-72
   for (int w = 0; w < n_wvl; ++w) {
     double lam = wvl[w];
@@ -515,6 +517,8 @@ int rcm_set_repwvl_tables(rcm_ensemble *h, int n_tpert, int n_species, int n_wvl
     pnum[w] = weight[w] * 2 * hP * std::pow(cL, 2);
     lam5[w] = std::pow(lam, 5);
     lkb[w] = lam * kB;
+    rw_xc[w] = (6.62607e-34 * 299792458.0) / lkb[w];  // the lane-pair kernels' form (planck_mono_fast)
+    rw_sc[w] = pnum[w] / lam5[w] / 1e9;
   }
   int rc = 0;
   rc = rc ? rc : dev_upload(h, (double **)&d.xsec, xt.data(), xt.size());
@@ -523,6 +527,8 @@ int rcm_set_repwvl_tables(rcm_ensemble *h, int n_tpert, int n_species, int n_wvl
   rc = rc ? rc : dev_upload(h, (double **)&d.pnum, pnum.data(), (size_t)n_wvl);
   rc = rc ? rc : dev_upload(h, (double **)&d.lam5, lam5.data(), (size_t)n_wvl);
   rc = rc ? rc : dev_upload(h, (double **)&d.lkb, lkb.data(), (size_t)n_wvl);
+  rc = rc ? rc : dev_upload(h, (double **)&d.rw_xc, rw_xc.data(), (size_t)n_wvl);
+  rc = rc ? rc : dev_upload(h, (double **)&d.rw_sc, rw_sc.data(), (size_t)n_wvl);
   if (rc) return rc;
   h->p_grid.assign(p_grid, p_grid + n_p);
   d.n_tpert = n_tpert, d.n_species = n_species, d.n_p = n_p, d.n_wvl = n_wvl;

@@ -79,6 +79,7 @@ struct Dev {
   long lbl_ld;
   // repwvl: xsec[t][s][p][w] (wavelength fastest)
   const double *xsec, *t_ref, *t_pert, *delP, *numDens, *pnum, *lam5, *lkb;
+  const double *rw_xc, *rw_sc;  // per wavelength: h*c/(lambda*kB) and pnum/lam5/1e9 (planck_mono_fast), host-formed
   const int *ip;
   int n_tpert, n_species, n_p, n_wvl;
   unsigned species_mask;
@@ -605,8 +606,8 @@ struct RepwvlPairLds {
   double delT[2][NH], delP[2][NH], numDens[2][NH];
   double vmr[2][RCM_NSPEC_REPWVL][NH];
   double cloud_tau;
-  int it[2][NH], ip[2][NH];
-  int cloud_k[2];  // position of the cloud layer in the lane's ordering (outside [0, NH): none)
+  unsigned xoff[2][NH];  // byte offset of xsec[it][0][ip][0]: the (T, p) bracket of the layer (:229-232)
+  int cloud_k[2];        // position of the cloud layer in the lane's ordering (outside [0, NH): none)
 };
 
 // Fills the LDS image of column `col`: per (parity, position) the temperature bracket of read_tau
@@ -627,8 +628,7 @@ __device__ __forceinline__ void repwvl_pair_image(const Dev &d, int col, int lan
       const double *tp = d.t_pert;
       const int it = lower_pos_dev([&](int j) { return tr + tp[j]; }, d.n_tpert, midT);  // :229-232
       const double t0 = tr + tp[it], t1 = tr + tp[it + 1];
-      s.it[q][k] = it;
-      s.ip[q][k] = ip;
+      s.xoff[q][k] = (unsigned)(((size_t)it * d.n_species * d.n_p + ip) * d.n_wvl * sizeof(double));
       s.delT[q][k] = (midT - t0) / (t1 - t0);  // :239
       s.delP[q][k] = d.delP[layer];
       s.numDens[q][k] = d.numDens[layer];
@@ -653,24 +653,28 @@ __device__ __forceinline__ void repwvl_pair_image(const Dev &d, int col, int lan
 template <int CUBE>
 __device__ __forceinline__ void repwvl_pair_point(const Dev &d, const RepwvlPairLds &s, int p, int w, int lane,
                                                   double (*st)[64], double (&acc1)[NH + 1], double (&acc2)[NH]) {
-  const size_t ld = d.n_wvl;
+  // xsec[t][s][p][w]: the four corners of a bracket sit at fixed distances (next pressure: n_wvl, next
+  // temperature: n_species*n_p*n_wvl), so four scalar bases + one 32-bit byte offset per (layer, species)
+  // address them (the table is < 4 GiB, rcm_set_repwvl_tables checks)
+  const unsigned ld8 = (unsigned)d.n_wvl * 8u, sp8 = (unsigned)d.n_p * ld8;
+  const char *b00 = (const char *)d.xsec, *b01 = b00 + ld8;
+  const char *b10 = b00 + (size_t)d.n_species * sp8, *b11 = b10 + ld8;
   const int cloud_k = s.cloud_k[p];
   const double cloud_tau = s.cloud_tau;
   double tau[NH];
 #pragma unroll 1
   for (int k = 0; k < NH; ++k) {
-    const int it = s.it[p][k], ip = s.ip[p][k];
+    const unsigned vo = s.xoff[p][k] + (unsigned)w * 8u;
     const double delT = s.delT[p][k], delP = s.delP[p][k];
     double a = 0.0;
 #pragma unroll
     for (int sp = 0; sp < RCM_NSPEC_REPWVL; ++sp) {
       if (!((d.species_mask >> sp) & 1u)) continue;  // vmr == 0 everywhere: the term is +0
-      const double *x0 = d.xsec + (((size_t)it * d.n_species + sp) * d.n_p + ip) * ld + w;
-      const double *x1 = d.xsec + (((size_t)(it + 1) * d.n_species + sp) * d.n_p + ip) * ld + w;
-      const double c0 = x0[0];                   // :235
-      const double cT = x1[0] - c0;              // :236
-      const double cP = x0[ld] - c0;             // :237
-      const double cPT = x1[ld] - cP - cT - c0;  // :238
+      const unsigned v = vo + (unsigned)sp * sp8;
+      const double c0 = *(const double *)(b00 + v);                   // :235
+      const double cT = *(const double *)(b10 + v) - c0;              // :236
+      const double cP = *(const double *)(b01 + v) - c0;              // :237
+      const double cPT = *(const double *)(b11 + v) - cP - cT - c0;  // :238
       const double xs = c0 + cT * delT + cP * delP + cPT * delT * delP;  // :241
       a += xs * s.vmr[p][sp][k];                 // :244
     }
@@ -680,8 +684,8 @@ __device__ __forceinline__ void repwvl_pair_point(const Dev &d, const RepwvlPair
   }
 #pragma unroll
   for (int k = 0; k < NH; ++k) tau[k] = st[k][lane];
-  const double xc = (6.62607e-34 * 299792458.0) / d.lkb[w];  // h*c/(lambda*kB), main.cpp:70-72,191
-  const double sc = d.pnum[w] / d.lam5[w] / 1e9;              // weight*2*h*c^2/lambda^5/1e9, main.cpp:190-191
+  const double xc = d.rw_xc[w];  // h*c/(lambda*kB), main.cpp:70-72,191
+  const double sc = d.rw_sc[w];  // weight*2*h*c^2/lambda^5/1e9, main.cpp:190-191
 #pragma unroll 1
   for (int k = 0; k <= NH; ++k) st[k][lane] = planck_mono_fast(xc, sc, s.T[p][k], s.rT[p][k]);
   double B[NH];
