@@ -34,8 +34,13 @@ def build(force=False, verbose=False):
         subprocess.run(cmd, check=True)
     main_src = os.path.join(CSRC, "rcm_main.cpp")
     if os.path.exists(main_src) and (force or _newer(MAIN, [main_src, LIB])):
-        subprocess.run(["g++", "-O2", "-std=c++17", "-I" + os.path.join(ROOT, "include"), "-o", MAIN, main_src,
-                        "-L" + PKG, "-lrcm_hip", "-Wl,-rpath,$ORIGIN"], check=True)
+        cmd = ["g++", "-O2", "-std=c++17", "-I" + os.path.join(ROOT, "include"), "-o", MAIN, main_src,
+               "-L" + PKG, "-lrcm_hip", "-Wl,-rpath,$ORIGIN"]
+        rocm = os.environ.get("ROCM_PATH", "/opt/rocm")
+        if os.path.exists(os.path.join(rocm, "include", "rccl", "rccl.h")):  # --devices: one RCCL all-gather
+            cmd += ["-DRCM_WITH_RCCL", "-D__HIP_PLATFORM_AMD__", "-I" + os.path.join(rocm, "include"),
+                    "-L" + os.path.join(rocm, "lib"), "-lrccl", "-lamdhip64", "-Wl,-rpath," + os.path.join(rocm, "lib")]
+        subprocess.run(cmd, check=True)
     return LIB
 
 

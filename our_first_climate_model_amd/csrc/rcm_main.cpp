@@ -9,13 +9,19 @@
 // column is replicated into a CO2 sweep and column 0.. are integrated together.
 //
 //   rcm_main [--atm F] [--table F.rtab | --lbl-dir D [--lbl-cache F]] [--steps N] [--output-steps K]
-//            [--co2-factor X] [--ncol N] [--tsfc T] [--tau-s X] [--output F] [--device I]
-//            [--print-cols a,b,..] [--equilibrium TOL_K] [--restart F] [--checkpoint F]
+//            [--co2-factor X] [--ncol N] [--tsfc T] [--tau-s X] [--output F] [--device I | --devices a,b,..]
+//            [--print-cols a,b,..] [--equilibrium TOL_K] [--restart F] [--checkpoint F] [--gather-out F]
+// --devices: the ensemble is cut into contiguous blocks of ceil(ncol/n) columns, one handle per listed
+//            GPU, all driven from this one process (rcm_step only enqueues); at the end ONE RCCL
+//            all-gather over the GPUs collects (Tlayer[20], T_surface) of every column.
+//            A device listed twice gets two handles and the gather goes through the host instead.
+// --gather-out: the gathered state, one line per column: col,T_surface,Tlayer[0..19].
 // --lbl-cache: binary cache of the five ASCII tables (read if present, else written after parsing).
 // --print-cols: columns whose profile block is written at every output time (default 0).
 // --equilibrium: instead of a fixed count, step until the adjusted profile changes by <= TOL_K per
 //                step in every column (rcm_run_to_equilibrium), at most --steps iterations.
-// --restart / --checkpoint: resume from / write the binary restart file (rcm_checkpoint_*).
+// --restart / --checkpoint: resume from / write the binary restart file (rcm_checkpoint_*); with several
+//            handles each has its own file, F.0, F.1, ..
 #include <chrono>
 #include <cmath>
 #include <cstdio>
@@ -26,12 +32,18 @@
 
 #include "rcm.h"
 
+#ifdef RCM_WITH_RCCL
+#include <hip/hip_runtime_api.h>
+#include <rccl/rccl.h>
+#endif
+
 namespace {
 
 struct Options {
   std::string atm = "./repwvl_V2.01_cpp/test.atm";                // main.cpp:397
   std::string table = "./repwvl_V2.01_cpp/Reduced100Forcing.rtab"; // main.cpp:500 (flattened .nc)
-  std::string lbl_dir, lbl_cache, restart, checkpoint;
+  std::string lbl_dir, lbl_cache, restart, checkpoint, gather_out;
+  std::vector<int> devices;  // empty: the single --device, no gather
   std::vector<int> print_cols = {0};
   double equilibrium = -1;  // < 0: fixed step count
   std::string output = "output.txt";                               // main.cpp:105,512
@@ -79,6 +91,15 @@ Options parse(int argc, char **argv) {
     else if (a == "--restart") o.restart = val();
     else if (a == "--checkpoint") o.checkpoint = val();
     else if (a == "--equilibrium") o.equilibrium = std::atof(val());
+    else if (a == "--gather-out") o.gather_out = val();
+    else if (a == "--devices") {
+      for (const char *p = val(); *p;) {
+        char *e = nullptr;
+        o.devices.push_back((int)std::strtol(p, &e, 10));
+        if (e == p) break;
+        p = (*e == ',') ? e + 1 : e;
+      }
+    }
     else if (a == "--print-cols" || a == "--print-col") {
       o.print_cols.clear();
       for (const char *p = val(); *p;) {
@@ -95,6 +116,7 @@ Options parse(int argc, char **argv) {
   }
   bool ok = o.ncol >= 1 && o.steps >= 0 && o.output_steps >= 1 && !o.print_cols.empty();
   for (int c : o.print_cols) ok = ok && c >= 0 && c < o.ncol;
+  for (int dv : o.devices) ok = ok && dv >= 0;
   if (!ok) {
     std::fprintf(stderr, "rcm_main: bad option value\n");
     std::exit(2);
@@ -138,6 +160,92 @@ void load_lbl(const std::string &dir, int nlayer, std::vector<double> &wvl, std:
   }
 }
 
+
+struct Shard {
+  rcm_ensemble *h = nullptr;
+  int device = 0, lo = 0, hi = 0;  // columns [lo, hi) of the ensemble
+};
+
+// (Tlayer[0..nlayer-1], T_surface) of every column, [ncol][nlev], from all handles.
+// Distinct GPUs: rcm_pack_state on each, then ONE ncclAllGather of equal (zero-padded) blocks over
+// xGMI -- every GPU ends with the whole ensemble, GPU 0's copy comes back.  Otherwise: through the host.
+const char *gather(std::vector<Shard> &shards, int ncol, int nlev, std::vector<double> &full) {
+  full.assign((size_t)ncol * nlev, 0.0);
+  const int n = (int)shards.size();
+  bool distinct = true;
+  for (int a = 0; a < n; ++a)
+    for (int b = a + 1; b < n; ++b) distinct = distinct && shards[a].device != shards[b].device;
+#ifdef RCM_WITH_RCCL
+  if (distinct) {
+    auto hipck = [](hipError_t e, const char *what) {
+      if (e != hipSuccess) {
+        std::fprintf(stderr, "rcm_main: %s: %s\n", what, hipGetErrorString(e));
+        std::exit(1);
+      }
+    };
+    auto ncclck = [](ncclResult_t e, const char *what) {
+      if (e != ncclSuccess) {
+        std::fprintf(stderr, "rcm_main: %s: %s\n", what, ncclGetErrorString(e));
+        std::exit(1);
+      }
+    };
+    int per = 0;
+    for (const Shard &sh : shards) per = std::max(per, sh.hi - sh.lo);
+    const size_t blk = (size_t)per * nlev;
+    std::vector<int> devs(n);
+    std::vector<ncclComm_t> comms(n);
+    std::vector<hipStream_t> streams(n);
+    std::vector<double *> send(n), recv(n);
+    for (int r = 0; r < n; ++r) devs[r] = shards[r].device;
+    ncclck(ncclCommInitAll(comms.data(), n, devs.data()), "ncclCommInitAll");
+    for (int r = 0; r < n; ++r) {
+      hipck(hipSetDevice(devs[r]), "hipSetDevice");
+      hipck(hipStreamCreate(&streams[r]), "hipStreamCreate");
+      hipck(hipMalloc((void **)&send[r], blk * sizeof(double)), "hipMalloc");
+      hipck(hipMalloc((void **)&recv[r], blk * n * sizeof(double)), "hipMalloc");
+      hipck(hipMemset(send[r], 0, blk * sizeof(double)), "hipMemset");
+      CK(rcm_pack_state(shards[r].h, send[r]));
+      CK(rcm_sync(shards[r].h));  // the pack runs on the handle's stream, the collective on ours
+    }
+    ncclck(ncclGroupStart(), "ncclGroupStart");
+    for (int r = 0; r < n; ++r)
+      ncclck(ncclAllGather(send[r], recv[r], blk, ncclDouble, comms[r], streams[r]), "ncclAllGather");
+    ncclck(ncclGroupEnd(), "ncclGroupEnd");
+    for (int r = 0; r < n; ++r) {
+      hipck(hipSetDevice(devs[r]), "hipSetDevice");
+      hipck(hipStreamSynchronize(streams[r]), "hipStreamSynchronize");
+    }
+    std::vector<double> all(blk * n);
+    hipck(hipSetDevice(devs[0]), "hipSetDevice");
+    hipck(hipMemcpy(all.data(), recv[0], all.size() * sizeof(double), hipMemcpyDeviceToHost), "hipMemcpy");
+    for (int r = 0; r < n; ++r) {
+      std::copy(all.begin() + r * blk, all.begin() + r * blk + (size_t)(shards[r].hi - shards[r].lo) * nlev,
+                full.begin() + (size_t)shards[r].lo * nlev);
+      hipck(hipSetDevice(devs[r]), "hipSetDevice");
+      (void)hipFree(send[r]);
+      (void)hipFree(recv[r]);
+      (void)hipStreamDestroy(streams[r]);
+      ncclCommDestroy(comms[r]);
+    }
+    return "RCCL (one all-gather)";
+  }
+#endif
+  (void)distinct;
+  const int nl = nlev - 1;
+  std::vector<double> T, Ts;
+  for (Shard &sh : shards) {
+    const int m = sh.hi - sh.lo;
+    T.resize((size_t)m * nl), Ts.resize(m);
+    CK(rcm_get_state(sh.h, T.data(), Ts.data(), nullptr, nullptr));
+    for (int c = 0; c < m; ++c) {
+      double *row = &full[(size_t)(sh.lo + c) * nlev];
+      std::copy(T.begin() + (size_t)c * nl, T.begin() + (size_t)(c + 1) * nl, row);
+      row[nl] = Ts[c];
+    }
+  }
+  return "the host (no RCCL in this build, or a GPU listed twice)";
+}
+
 }  // namespace
 
 int main(int argc, char **argv) {
@@ -179,9 +287,28 @@ int main(int argc, char **argv) {
   }
 
   // ---- ensemble + optical-depth tables: main.cpp:494-504 -------------------------------------
-  rcm_ensemble *h = nullptr;
-  CK(rcm_create(o.ncol, nlayer, nangle, o.device, nullptr, &h));
-  CK(rcm_set_grid(h, plevel.data()));
+  // one handle per device entry, contiguous blocks of ceil(ncol/n) columns (empty blocks are dropped)
+  std::vector<Shard> shards;
+  {
+    const std::vector<int> devs = o.devices.empty() ? std::vector<int>{o.device} : o.devices;
+    const int per = (o.ncol + (int)devs.size() - 1) / (int)devs.size();
+    for (size_t r = 0; r < devs.size(); ++r) {
+      Shard sh;
+      sh.device = devs[r];
+      sh.lo = std::min((int)r * per, o.ncol);
+      sh.hi = std::min(sh.lo + per, o.ncol);
+      if (sh.hi > sh.lo) shards.push_back(sh);
+    }
+  }
+  for (Shard &sh : shards) {
+    CK(rcm_create(sh.hi - sh.lo, nlayer, nangle, sh.device, nullptr, &sh.h));
+    CK(rcm_set_grid(sh.h, plevel.data()));
+  }
+  auto shard_of = [&](int c) -> Shard & {
+    for (Shard &sh : shards)
+      if (c >= sh.lo && c < sh.hi) return sh;
+    return shards[0];
+  };
   if (lbl) {
     std::vector<double> wvl;
     std::vector<std::vector<double>> tabs;
@@ -197,7 +324,7 @@ int main(int argc, char **argv) {
         return 1;
       }
       for (int s = 0; s < RCM_NSPEC_LBL; ++s) tp[s] = ct + (size_t)s * n_nodes * nlayer;
-      CK(rcm_set_lbl_tables(h, n_nodes, cw, tp, h2o_ref.data()));
+      for (Shard &sh : shards) CK(rcm_set_lbl_tables(sh.h, n_nodes, cw, tp, h2o_ref.data()));
       rcm_free(cw);
       rcm_free(ct);
     } else {
@@ -208,7 +335,7 @@ int main(int argc, char **argv) {
       load_lbl(o.lbl_dir, nlayer, wvl, tabs);
       for (int s = 0; s < RCM_NSPEC_LBL; ++s) tp[s] = tabs[s].data();
       if (!o.lbl_cache.empty()) CK(rcm_lbl_cache_write(o.lbl_cache.c_str(), (int)wvl.size(), nlayer, wvl.data(), tp));
-      CK(rcm_set_lbl_tables(h, (int)wvl.size(), wvl.data(), tp, h2o_ref.data()));
+      for (Shard &sh : shards) CK(rcm_set_lbl_tables(sh.h, (int)wvl.size(), wvl.data(), tp, h2o_ref.data()));
     }
   } else {
     long long dims[4];
@@ -217,7 +344,8 @@ int main(int argc, char **argv) {
     const size_t nt = dims[0], ns = dims[1], nw = dims[2], np = dims[3];
     const double *p_grid = blob, *t_ref = p_grid + np, *t_pert = t_ref + np, *vmrs_ref = t_pert + nt,
                  *wvl = vmrs_ref + ns * np, *weight = wvl + nw, *xsec = weight + nw;
-    CK(rcm_set_repwvl_tables(h, (int)nt, (int)ns, (int)nw, (int)np, p_grid, t_ref, t_pert, wvl, weight, xsec));
+    for (Shard &sh : shards)
+      CK(rcm_set_repwvl_tables(sh.h, (int)nt, (int)ns, (int)nw, (int)np, p_grid, t_ref, t_pert, wvl, weight, xsec));
     rcm_free(blob);
   }
 
@@ -225,9 +353,14 @@ int main(int argc, char **argv) {
   double solar[7];
   const double mu_s = std::cos(60 * M_PI / 180.0);  // main.cpp:87
   CK(rcm_solar_setup(o.tau_s, mu_s, 20, 0.85, 0.12, (double)0.5f, 1361.0, solar));
-  CK(rcm_set_forcing(h, solar[6], 17, o.tau_s / 2.0));  // main.cpp:92, 267
-  CK(rcm_set_columns(h, T0.data(), Ts0.data(), gas.data(), relhum.data()));
-  if (!o.restart.empty()) CK(rcm_checkpoint_load(h, o.restart.c_str()));
+  auto shard_file = [&](const std::string &f, size_t r) { return shards.size() == 1 ? f : f + "." + std::to_string(r); };
+  for (size_t r = 0; r < shards.size(); ++r) {
+    Shard &sh = shards[r];
+    CK(rcm_set_forcing(sh.h, solar[6], 17, o.tau_s / 2.0));  // main.cpp:92, 267
+    CK(rcm_set_columns(sh.h, &T0[(size_t)sh.lo * nlayer], &Ts0[sh.lo], &gas[(size_t)sh.lo * ngas * nlayer],
+                       &relhum[(size_t)sh.lo * nlayer]));
+    if (!o.restart.empty()) CK(rcm_checkpoint_load(sh.h, shard_file(o.restart, r).c_str()));
+  }
   FILE *out = std::fopen(o.output.c_str(), "a");  // main.cpp:512 (append)
   if (!out) {
     std::fprintf(stderr, "rcm_main: cannot open %s\n", o.output.c_str());
@@ -241,7 +374,8 @@ int main(int argc, char **argv) {
   const auto t0 = std::chrono::steady_clock::now();
   auto write_blocks = [&]() {  // main.cpp:543-546 for every selected column
     for (int c : o.print_cols) {
-      CK(rcm_get_profile(h, c, Tadj.data(), theta.data(), &time_h));
+      Shard &sh = shard_of(c);
+      CK(rcm_get_profile(sh.h, c - sh.lo, Tadj.data(), theta.data(), &time_h));
       CK(rcm_write_profile(out, nlayer, player.data(), Tadj.data(), theta.data(), time_h));
     }
   };
@@ -251,34 +385,63 @@ int main(int argc, char **argv) {
     if (i % o.output_steps == 0) write_blocks();  // before this iteration's radiative transfer
     const int next_out = (i / o.output_steps + 1) * o.output_steps;
     const int run = std::min(next_out, o.steps + 1) - i;  // iterations until the next output or the end
+    for (Shard &sh : shards) CK(rcm_step(sh.h, run));  // only enqueues: the GPUs run side by side
+    i += run;
     if (o.equilibrium >= 0) {
-      int done = 0;
-      CK(rcm_run_to_equilibrium(h, o.equilibrium, run, run, &done, &resid));
-      i += done;
+      // the criterion of rcm_run_to_equilibrium on the WHOLE ensemble: worst column of all handles
+      resid = 0;
+      std::vector<double> r;
+      for (Shard &sh : shards) {
+        r.resize(sh.hi - sh.lo);
+        CK(rcm_get_residual(sh.h, r.data()));
+        for (double v : r) resid = std::max(resid, v);
+      }
       if (resid <= o.equilibrium) {
         write_blocks();  // the equilibrium profile
         break;
       }
-    } else {
-      CK(rcm_step(h, run));
-      i += run;
     }
   }
   const int iterations = std::min(i, o.steps + 1);
-  CK(rcm_sync(h));
+  for (Shard &sh : shards) CK(rcm_sync(sh.h));
   const double secs = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
   std::fclose(out);
 
-  if (!o.checkpoint.empty()) CK(rcm_checkpoint_save(h, o.checkpoint.c_str()));
+  for (size_t r = 0; r < shards.size(); ++r)
+    if (!o.checkpoint.empty()) CK(rcm_checkpoint_save(shards[r].h, shard_file(o.checkpoint, r).c_str()));
   std::vector<double> Tsfc(o.ncol);
   std::vector<float> tm(o.ncol);
-  CK(rcm_get_state(h, nullptr, Tsfc.data(), tm.data(), nullptr));
-  std::fprintf(stderr, "rcm_main: %d column(s) x %d iterations (%d spectral points) in %.3f s = %.1f column-timesteps/s\n",
-               o.ncol, iterations, rcm_nspectral(h), secs, o.ncol * (double)iterations / secs);
+  for (Shard &sh : shards) CK(rcm_get_state(sh.h, nullptr, &Tsfc[sh.lo], &tm[sh.lo], nullptr));
+  std::fprintf(stderr, "rcm_main: %d column(s) x %d iterations (%d spectral points) on %zu handle(s) in %.3f s = %.1f column-timesteps/s\n",
+               o.ncol, iterations, rcm_nspectral(shards[0].h), shards.size(), secs, o.ncol * (double)iterations / secs);
   if (o.equilibrium >= 0)
     std::fprintf(stderr, "rcm_main: equilibrium residual %.3e K/step (tolerance %.3e)\n", resid, o.equilibrium);
   for (int c : o.print_cols)
     std::fprintf(stderr, "rcm_main: column %d: T_surface %.10f K, time %.6f h\n", c, Tsfc[c], tm[c]);
-  CK(rcm_destroy(h));
+  if (!o.devices.empty() || !o.gather_out.empty()) {
+    std::vector<double> full;
+    const char *how = gather(shards, o.ncol, nlayer + 1, full);
+    std::fprintf(stderr, "rcm_main: gathered %d x %d state values over %s\n", o.ncol, nlayer + 1, how);
+    for (int c : o.print_cols)
+      if (full[(size_t)c * (nlayer + 1) + nlayer] != Tsfc[c]) {
+        std::fprintf(stderr, "rcm_main: gathered T_surface of column %d differs from the handle's\n", c);
+        return 1;
+      }
+    if (!o.gather_out.empty()) {
+      FILE *g = std::fopen(o.gather_out.c_str(), "w");
+      if (!g) {
+        std::fprintf(stderr, "rcm_main: cannot open %s\n", o.gather_out.c_str());
+        return 1;
+      }
+      for (int c = 0; c < o.ncol; ++c) {
+        const double *row = &full[(size_t)c * (nlayer + 1)];
+        std::fprintf(g, "%d,%.17g", c, row[nlayer]);
+        for (int l = 0; l < nlayer; ++l) std::fprintf(g, ",%.17g", row[l]);
+        std::fputc('\n', g);
+      }
+      std::fclose(g);
+    }
+  }
+  for (Shard &sh : shards) CK(rcm_destroy(sh.h));
   return 0;
 }

@@ -454,6 +454,48 @@ def test_driver_restart_cache_equilibrium_and_column_selection(pkg, olib, golden
     assert (tmp_path / "l1.txt").read_text() == (tmp_path / "l2.txt").read_text()
 
 
+def test_driver_sharded_over_handles_and_gathered(pkg, golden, tmp_path):
+    """rcm_main --devices: the ensemble cut over several handles gives the state of the one-handle run,
+    column for column (columns are independent; to the last bits of the spectral sum); the gather is ONE RCCL all-gather when the GPUs are
+    distinct (here: one rank, the only GPU of the box) and goes through the host for a GPU listed twice.
+    Also the global equilibrium criterion: the same stopping iteration however the ensemble is cut."""
+    base = ["--atm", os.path.join(golden, "test.atm"), "--table", os.path.join(golden, "Reduced10Forcing.rtab"),
+            "--ncol", "7", "--steps", "12", "--output-steps", "100"]
+    r1 = _run_driver(base + ["--gather-out", "g1.txt", "--output", "o1.txt"], tmp_path)            # one handle, host
+    rr = _run_driver(base + ["--devices", "0", "--gather-out", "gr.txt", "--output", "or.txt"], tmp_path)
+    r2 = _run_driver(base + ["--devices", "0,0", "--gather-out", "g2.txt", "--output", "o2.txt"], tmp_path)
+    r3 = _run_driver(base + ["--devices", "0,0,0", "--gather-out", "g3.txt", "--output", "o3.txt",
+                             "--print-cols", "0,6"], tmp_path)
+    assert "over RCCL (one all-gather)" in rr.stderr and "over the host" in r2.stderr
+    assert "on 2 handle(s)" in r2.stderr and "on 3 handle(s)" in r3.stderr
+    g1 = (tmp_path / "g1.txt").read_text()
+    assert len(g1.splitlines()) == 7 and len(g1.splitlines()[0].split(",")) == 22
+    assert (tmp_path / "gr.txt").read_text() == g1  # same cut, the gather over RCCL: same bits
+    rows = np.array([[float(v) for v in ln.split(",")] for ln in g1.splitlines()])
+    for other in ("g2.txt", "g3.txt"):
+        # another cut puts a column's wavelengths into other waves of the flattened kernel: the spectral
+        # sum is taken in another (fixed) order, so the last bits may differ -- nothing else may
+        got = np.array([[float(v) for v in ln.split(",")] for ln in (tmp_path / other).read_text().splitlines()])
+        assert got.shape == rows.shape and H.max_abs(got, rows) <= 1e-10
+    assert (tmp_path / "o1.txt").read_text() == (tmp_path / "o2.txt").read_text()
+    # the library's own answer for the same ensemble (the driver's sweep: CO2 x linspace(0.5, 4), nothing else)
+    atm, _ = pkg.atm_load(os.path.join(golden, "test.atm"))
+    spec = pkg.EnsembleSpec(co2_factor=np.linspace(0.5, 4.0, 7), rh_scale=np.ones(7), T_surface0=np.full(7, 288.2))
+    inp = dict(mode="repwvl", ncol=7, cols=pkg.build_columns(atm, spec, "repwvl"), solar=pkg.default_solar()["solar_irr"],
+               table=pkg.read_rtab(os.path.join(golden, "Reduced10Forcing.rtab")))
+    g = H.gpu_ensemble(pkg, inp)
+    g.step(13)
+    st = g.get_state()
+    np.testing.assert_array_equal(rows[:, 1], st["T_surface"])
+    np.testing.assert_array_equal(rows[:, 2:], st["Tlayer"])
+    # equilibrium: worst column of the WHOLE ensemble decides, for every cut the same iteration
+    eq = base[:6] + ["--steps", "400", "--output-steps", "25", "--equilibrium", "0.2"]
+    e1 = _run_driver(eq + ["--output", "q1.txt"], tmp_path)
+    e2 = _run_driver(eq + ["--devices", "0,0", "--output", "q2.txt"], tmp_path)
+    n1 = e1.stderr.split(" iterations")[0].split("x ")[-1]
+    assert f"x {n1} iterations" in e2.stderr and 25 <= int(n1) < 401
+
+
 def test_full_spectrum_step_is_consistent_with_its_own_fluxes(pkg, big):
     # size-independent identities of main.cpp:337-341, 156-176 on the full 131 071-band ensemble:
     # dE from the flux profiles, solar heating entering the lowest layer linearly, dt from the SIGNED max,
