@@ -138,8 +138,9 @@ int rcm_get_fluxes(rcm_ensemble *h, double *E_down, double *E_up, double *dE);
 /* What output_conv (main.cpp:102-114) would print for column `col` at the top of the next
  * iteration: adjusted Tlayer[nlayer], sorted theta[nlayer], time.  Does not modify the state. */
 int rcm_get_profile(rcm_ensemble *h, int col, double *Tlayer_adj, double *theta, float *time_h);
-/* Layer optical depths of column `col` at its current state, [nspectral][nlayer], cloud
- * included -- what read_tau + cloud_into_tau (or the lbl assembly) hand to radiative_transfer. */
+/* Layer optical depths of column `col`, [nspectral][nlayer], cloud included -- what read_tau +
+ * cloud_into_tau (or the lbl assembly) handed to the most recent radiative_transfer; before the first
+ * step: what they will hand to it (the initial, not yet adjusted profile, main.cpp:500). */
 int rcm_get_tau(rcm_ensemble *h, int col, double *tau);
 /* Current gas block [ncol][ngas][nlayer] (H2O row follows the feedback). */
 int rcm_get_gas(rcm_ensemble *h, double *gas);

@@ -474,6 +474,7 @@ struct orc_ensemble {
   double dp;
   double *plevel, *player, *conv;
   double *solar_irr, *cloud_tau, *resid, *Tprev; /* per column */
+  double *Ttau; /* [ncol][nlayer]: the profile the optical depths were last formed from */
   int *cloud_layer;
   /* repwvl */
   int n_tpert, n_species, n_wvl, n_p;
@@ -509,6 +510,7 @@ int orc_create(int ncol, int nlayer, int nangle, orc_ensemble **out) {
   h->cloud_layer = (int *)calloc(ncol, sizeof(int));
   h->resid = (double *)calloc(ncol, sizeof(double));
   h->Tprev = (double *)calloc((size_t)ncol * nlayer, sizeof(double));
+  h->Ttau = (double *)calloc((size_t)ncol * nlayer, sizeof(double));
   for (int c = 0; c < ncol; ++c) {
     h->cloud_layer[c] = 17;      /* main.cpp:92 */
     h->cloud_tau[c] = 2.0 / 2.0; /* main.cpp:267 */
@@ -528,7 +530,7 @@ int orc_create(int ncol, int nlayer, int nangle, orc_ensemble **out) {
 int orc_destroy(orc_ensemble *h) {
   if (!h) return -1;
   free(h->plevel); free(h->player); free(h->conv);
-  free(h->solar_irr); free(h->cloud_tau); free(h->cloud_layer); free(h->resid); free(h->Tprev);
+  free(h->solar_irr); free(h->cloud_tau); free(h->cloud_layer); free(h->resid); free(h->Tprev); free(h->Ttau);
   free(h->p_grid); free(h->t_ref); free(h->t_pert); free(h->wvl); free(h->weight); free(h->xsec);
   free(h->lbl_wvl); free(h->h2o_ref);
   for (int s = 0; s < ORC_NSPEC_LBL; ++s) free(h->lbl_tab[s]);
@@ -645,6 +647,7 @@ int orc_threads_used(orc_ensemble *h) { return h ? h->threads_used : -1; }
 /* optical depths for one column at its current state: main.cpp:500-504 / 564-568 */
 static void column_tau(const orc_ensemble *h, int c, double *tau) {
   const int nl = h->nlayer;
+  memcpy(h->Ttau + (size_t)c * nl, h->T + (size_t)c * nl, nl * sizeof(double));
   const double *gas = h->gas + (size_t)c * h->ngas * nl;
   int nspec;
   if (h->mode == ORC_MODE_REPWVL) {
@@ -757,9 +760,21 @@ int orc_get_profile(orc_ensemble *h, int col, double *Tlayer_adj, double *theta,
   return 0;
 }
 
+/* The optical depths of the most recent radiative transfer (before the first step: those it will
+ * use), i.e. formed from the profile column_tau last saw, with the current gas block. */
 int orc_get_tau(orc_ensemble *h, int col, double *tau) {
   if (!h || h->mode < 0 || col < 0 || col >= h->ncol || !tau) return -1;
-  column_tau(h, col, tau);
+  const int nl = h->nlayer;
+  double keep[256], *T = h->T + (size_t)col * nl;
+  if (nl > 256) return -1;
+  if (h->step_index > 0) { /* evaluate at the saved profile, leave the state as it was */
+    memcpy(keep, T, nl * sizeof(double));
+    memcpy(T, h->Ttau + (size_t)col * nl, nl * sizeof(double));
+    column_tau(h, col, tau);
+    memcpy(T, keep, nl * sizeof(double));
+  } else {
+    column_tau(h, col, tau);
+  }
   return 0;
 }
 

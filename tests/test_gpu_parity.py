@@ -593,3 +593,16 @@ def test_flattened_repwvl_kernel_segment_boundaries(pkg, olib, table, monkeypatc
             g.close()
         for k in res[0]:
             assert H.max_abs(res[0][k], res[1][k]) <= FLUX_TIGHT
+
+
+def test_randomised_configurations_against_oracle(pkg, olib):
+    """tools/fuzz_parity.py, 60 seeded draws of (path, ensemble size, spectrum length incl. 2/33/65/odd sizes,
+    angle count, forced chunking, cloud layer incl. none, 1-3 steps): fluxes <= 2e-9 W/m2, temperatures
+    <= 1e-9 K, optical depths of the last radiative transfer <= 1e-12 relative, float time identical."""
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import fuzz_parity
+    lines = []
+    bad, worst = fuzz_parity.run(60, 20260104, lines.append)
+    assert bad == 0, "\n".join(ln for ln in lines if "FAIL" in ln)
+    assert worst["flux"] <= 2e-9 and worst["T"] <= 1e-9 and worst["tau"] <= 1e-12

@@ -1,0 +1,77 @@
+#!/usr/bin/env python3
+"""Randomised GPU-vs-oracle parity sweep (run on the MI355X box): ensemble size, spectrum length, angle
+count, spectral chunking, cloud position/depth and step count are drawn from a seeded generator; fluxes,
+optical depths and temperatures are compared with the CPU oracle at the tolerances of the tests.
+
+    python tools/fuzz_parity.py [cases=120] [seed=1]
+
+Prints one line per case and a summary; exit code 1 if any case is outside the tolerance."""
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import numpy as np
+import torch  # noqa: F401  (one HIP runtime per process: torch first)
+import helpers as H
+import oracle_lib as ol
+import our_first_climate_model_amd as pkg
+
+FLUX_TOL, T_TOL, TAU_RTOL = 2e-9, 1e-9, 1e-12  # tests/test_gpu_parity.py
+
+
+def run(ncases=120, seed=1, log=print):
+    """Returns (cases outside the tolerance, worst deviations)."""
+    rng = np.random.default_rng(seed)
+    olib = ol.load()
+    worst = dict(flux=0.0, T=0.0, tau=0.0)
+    bad = 0
+    t_start = time.time()
+    for case in range(ncases):
+        mode = "lbl" if rng.random() < 0.6 else "repwvl"
+        nangle = int(rng.choice([30, 30, 30, 1, 2, 3, 5, 7, 13, 29, 31, 45, 64]))
+        if mode == "lbl":
+            n_nodes = int(rng.choice([2, 3, 33, 34, 64, 65, 66, 97, 129, int(rng.integers(2, 6000))]))
+            ncol = int(rng.integers(1, max(2, min(200, 150000 // max(n_nodes, 1)))))
+            inp = H.make_inputs(pkg, "lbl", ncol, n_nodes=n_nodes, atm="fpda.lbl.atm", perturb=bool(rng.random() < 0.8))
+            nspec = n_nodes - 1
+        else:
+            table = str(rng.choice(["Reduced10", "Reduced20", "Reduced100"]))
+            ncol = int(rng.integers(1, 120))
+            inp = H.make_inputs(pkg, "repwvl", ncol, table=table, perturb=bool(rng.random() < 0.8))
+            nspec = inp["table"]["n_wvl"]
+        inp["cloud_layer"] = int(rng.integers(-1, 20))
+        inp["cloud_tau"] = float(rng.choice([0.0, 1.0, 0.3, 25.0]))
+        steps = int(rng.integers(1, 4))
+        g = H.gpu_ensemble(pkg, inp, nangle=nangle)
+        chunks = 0
+        if rng.random() < 0.5:
+            chunks = int(rng.integers(1, max(2, (nspec + 31) // 32 + 1)))
+            g.set_spectral_chunks(chunks)
+        o = H.oracle_ensemble(olib, inp, nangle=nangle)
+        g.step(steps), o.step(steps)
+        fg, fo = g.get_fluxes(), o.get_fluxes()
+        e_flux = max(H.max_abs(fg[k], fo[k]) for k in fg)
+        sg, so = g.get_state(), o.get_state()
+        e_T = max(H.max_abs(sg["Tlayer"], so["Tlayer"]), H.max_abs(sg["T_surface"], so["T_surface"]))
+        col = int(rng.integers(0, ncol))
+        tg, to = g.get_tau(col), o.get_tau(col)
+        e_tau = float(np.max(np.abs(tg - to) / np.maximum(np.abs(to), 1e-300)))
+        same_time = bool(np.array_equal(sg["time_h"], so["time_h"]))
+        ok = e_flux <= FLUX_TOL and e_T <= T_TOL and e_tau <= TAU_RTOL and same_time
+        bad += not ok
+        worst["flux"], worst["T"], worst["tau"] = max(worst["flux"], e_flux), max(worst["T"], e_T), max(worst["tau"], e_tau)
+        log(f"{case:4d} {mode:6s} ncol={ncol:4d} nspec={nspec:5d} nangle={nangle:2d} chunks={chunks or 'auto':>5} "
+            f"used={g.get_spectral_chunks():4d} cloud=({inp['cloud_layer']:2d},{inp['cloud_tau']:4.1f}) steps={steps} "
+            f"dFlux={e_flux:.2e} dT={e_T:.2e} dtau={e_tau:.1e} time={'==' if same_time else '!='} {'ok' if ok else 'FAIL'}")
+        g.close()
+    log(f"{ncases} cases in {time.time() - t_start:.0f} s: {bad} outside tolerance; worst dFlux {worst['flux']:.2e} W/m^2, "
+        f"dT {worst['T']:.2e} K, dtau {worst['tau']:.1e} (relative)")
+    return bad, worst
+
+
+if __name__ == "__main__":
+    n_bad, _ = run(int(sys.argv[1]) if len(sys.argv) > 1 else 120, int(sys.argv[2]) if len(sys.argv) > 2 else 1)
+    sys.exit(1 if n_bad else 0)
