@@ -9,39 +9,16 @@
 namespace rcm {
 
 // ---------------------------------------------------------------------------------------------
-// exp(x) for the transmission t = exp(-tau/mu) (main.cpp:209), x <= 0 in normal use.
+// exp(x) for the transmission t = exp(-tau/mu) (main.cpp:209).
 //
-// EXPV 0: the ROCm device library's exp (reference-grade, ~1 ulp).
-// EXPV 1: shared-nothing ALU version: k = rint(x*log2e) by the 1.5*2^52 trick (the integer
-//         falls out of the low mantissa word for free), r = x - k*ln2 in two FMAs, degree-10
-//         near-minimax polynomial (max rel err 2.9e-16 + rounding), 2^k applied by an integer
-//         add into the exponent field.  x is clamped to [-708, 708] first so the result
-//         is a normal number and the exponent add cannot wrap: exp(-708) = 3e-308 stands in for
-//         everything smaller, which is indistinguishable in 1 - t and t*(L - B).
+// EXPV 0 (reference variants): the ROCm device library's exp (~1 ulp).
+// EXPV 1 (production): k = rint(y), y = x*log2(e), by the 1.5*2^52 trick (the integer falls out of the low
+//         mantissa word for free), f = y - k in one FMA, near-minimax polynomial for 2^f with constant
+//         term exactly 1, 2^k applied by v_ldexp_f64.
 // ---------------------------------------------------------------------------------------------
-__device__ __forceinline__ double exp_poly10(double x) {
-  constexpr double kLog2e = 0x1.71547652b82fep+0;
-  constexpr double kLn2Hi = 0x1.62e42fefa39efp-1;   // ln2 rounded to double
-  constexpr double kLn2Lo = 0x1.abc9e3b39803fp-56;  // ln2 - kLn2Hi
-  constexpr double kMagic = 0x1.8p+52;              // 1.5 * 2^52
-  x = fmax(x, -708.0);
-  x = fmin(x, 708.0);
-  const double z = fma(x, kLog2e, kMagic);
-  const double kf = z - kMagic;
-  double r = fma(kf, -kLn2Hi, x);
-  r = fma(kf, -kLn2Lo, r);
-  double p = kExpPoly10[10];
-#pragma unroll
-  for (int i = 9; i >= 0; --i) p = fma(p, r, kExpPoly10[i]);
-  // 2^k: add k to the biased exponent (bits 52..62 = bits 20..30 of the high word)
-  const int k = __double2loint(z);
-  const int hi = __double2hiint(p) + (int)((unsigned)k << 20);
-  return __hiloint2double(hi, __double2loint(p));
-}
-
-// Transmission t = exp(-tau * s) with the per-angle constants a1 = -s*log2(e), a2 = -s.
+// Transmission t = exp(-tau * s) with the per-angle constant a1 = -s*log2(e).
 // tau must already be clamped to [kTauMin, kTauMax] (once per band-layer, clamp_tau) so that
-// |k| < 2^31; k < -1022 is pinned there by an integer max (t ~ 1e-308 stands in for 0).
+// |k| < 2^31; v_ldexp_f64 takes care of k < -1022 (denormal, then 0).
 constexpr double kTauMin = -10.0;  // exp(+10*60) is still finite
 constexpr double kTauMax = 1.0e7;  // exp(-1e7) == 0 for every angle
 
@@ -53,24 +30,12 @@ __device__ __forceinline__ double clamp_tau(double tau) { return fmin(fmax(tau, 
                        // the oracle: flux deviation 1e-12..4e-11 W/m^2 for 10 and 9 alike, 3e-11..5e-11 for 8
                        // (3.8 % faster); the contract is 1e-6 W/m^2.
 #endif
-#ifndef RCM_EXP_LN2LO
-#define RCM_EXP_LN2LO 0  // second FMA of the range reduction (k * low bits of ln2): |k| * 2.3e-17 relative, not needed
-#endif
-
-#ifndef RCM_EXP_BASE2
-#define RCM_EXP_BASE2 1  // 1: polynomial for 2^f in f = y - k directly (one instruction fewer)
-#endif
-
-__device__ __forceinline__ double exp_trans(double tau, double a1, double a2) {
-  constexpr double kLn2Hi = 0x1.62e42fefa39efp-1;
+__device__ __forceinline__ double exp_trans(double tau, double a1) {
   constexpr double kMagic = 0x1.8p+52;
   const double z = fma(tau, a1, kMagic);  // low word of z = k = rint(-tau*s*log2e), two's complement
   const double kf = z - kMagic;
-#if RCM_EXP_BASE2
   // f = y - k with y = tau*a1 = -tau*s*log2(e): one FMA, exact up to the rounding of a1
   // (relative 1.1e-16 of y: <= 4e-15 of the result wherever t >= 1e-15)
-  (void)a2;
-  (void)kLn2Hi;
   const double f = fma(tau, a1, -kf);
 #if RCM_EXP_DEG == 8
   double q = kExp2Poly8[8];
@@ -85,23 +50,8 @@ __device__ __forceinline__ double exp_trans(double tau, double a1, double a2) {
 #pragma unroll
   for (int i = 9; i >= 0; --i) q = fma(q, f, kExp2Poly10[i]);
 #endif
-  return __builtin_amdgcn_ldexp(q, __double2loint(z));
-#endif
-  double r = fma(kf, -kLn2Hi, tau * a2);
-#if RCM_EXP_LN2LO
-  r = fma(kf, -0x1.abc9e3b39803fp-56, r);
-#endif
-#if RCM_EXP_DEG == 9
-  double p = kExpPoly9[9];
-#pragma unroll
-  for (int i = 8; i >= 0; --i) p = fma(p, r, kExpPoly9[i]);
-#else
-  double p = kExpPoly10[10];
-#pragma unroll
-  for (int i = 9; i >= 0; --i) p = fma(p, r, kExpPoly10[i]);
-#endif
   // v_ldexp_f64: one instruction, denormal/zero for k < -1022 (no integer clamp needed)
-  return __builtin_amdgcn_ldexp(p, __double2loint(z));
+  return __builtin_amdgcn_ldexp(q, __double2loint(z));
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -30,17 +30,8 @@ constexpr int WPB = 4;       // waves per block = columns per block (one per SIM
 #ifndef RCM_LB
 #define RCM_LB 1  // waves per SIMD the lbl RT kernel is register-allocated for (1: spills go to AGPRs, not scratch)
 #endif
-#ifndef RCM_B_LDS
-#define RCM_B_LDS 0  // 1: the sweeps re-read the Planck column from LDS; 0: it is hoisted into 42 VGPRs
-#endif
-#ifndef RCM_SCHED4
-#define RCM_SCHED4 0  // scheduling barrier after every 4th transmission exp
-#endif
 #ifndef RCM_PAIR_LB
 #define RCM_PAIR_LB 3  // waves per SIMD the lane-pair kernels are register-allocated for (<= 168 VGPRs)
-#endif
-#ifndef RCM_SHARED_EMISSION
-#define RCM_SHARED_EMISSION 1  // lane-pair sweeps: form (1-t)*B once per layer and angle, use it in both crossings
 #endif
 #ifndef RCM_PLK_HOIST
 #define RCM_PLK_HOIST 1  // decide the Planck regime once per band (wave vote) and run the loop branch-free
@@ -94,11 +85,6 @@ struct Dev {
 // grid lives in LDS, the 41 flux accumulators and the transmissions in VGPRs.
 __device__ __forceinline__ void sweep(const double (&t)[NL], const double (*B)[64], double cw,
                                       double (&Ed)[NLEV], double (&Eu)[NLEV]) {
-  // Compiler fence: B must be re-read from LDS in every sweep.  Without it the loads are hoisted
-  // out of the angle loop into 42 VGPRs and the kernel spills.
-#if RCM_B_LDS
-  asm volatile("" ::: "memory");
-#endif
   double L = 0.0;  // main.cpp:300
 #pragma unroll
   for (int l = 0; l < NL; ++l) {  // main.cpp:306-309
@@ -123,16 +109,9 @@ __device__ __forceinline__ void transmissions(const double (&tau)[NL], double in
 #pragma unroll
     for (int l = 0; l < NL; ++l) t[l] = exp(-tau[l] * inv_mu);
   } else {
-    const double a2 = -inv_mu, a1 = a2 * 0x1.71547652b82fep+0;
+    const double a1 = -inv_mu * 0x1.71547652b82fep+0;
 #pragma unroll
-    for (int l = 0; l < NL; ++l) {
-      t[l] = exp_trans(tau[l], a1, a2);
-      // Four independent exp chains are enough to cover the fp64 latency; letting the scheduler
-      // interleave all twenty inflates the live temporaries past 256 VGPRs and spills tau to scratch.
-#if RCM_SCHED4
-      if ((l & 3) == 3) __builtin_amdgcn_sched_barrier(0);
-#endif
-    }
+    for (int l = 0; l < NL; ++l) t[l] = exp_trans(tau[l], a1);
   }
 }
 
@@ -351,32 +330,22 @@ template <int DEPTH>
 __device__ __forceinline__ void pair_chain(const Dev &d, const double (&t)[NH], const double (&B)[NH],
                                            double Linit, int m, double (&acc1)[NH + 1], double (&acc2)[NH]) {
   const double cw = d.ang[d.nangle + ((m - 1) >> 1)];
-#if RCM_SHARED_EMISSION
   // A lane crosses each of its layers twice (phase 1 and phase 2) with the same transmission: the
   // layer's own emission (1-t)*B = alpha*B of main.cpp:307,312 is formed once and both crossings are
   // L = t*L + e: 5 instead of 6 instructions per layer and angle.
   double e[NH];
 #pragma unroll
   for (int k = 0; k < NH; ++k) e[k] = fma(-t[k], B[k], B[k]);
-#endif
   double L = Linit;  // its own flux contribution (main.cpp:302) is added once per band by the caller
 #pragma unroll
   for (int k = 0; k < NH; ++k) {
-#if RCM_SHARED_EMISSION
     L = fma(t[k], L, e[k]);
-#else
-    L = fma(t[k], L - B[k], B[k]);
-#endif
     acc1[k + 1] = fma(cw, L, acc1[k + 1]);
   }
   L = pair_swap(L);  // level 10: the down radiance moves to the odd lane, the up radiance to the even lane
 #pragma unroll
   for (int k = NH - 1; k >= 0; --k) {
-#if RCM_SHARED_EMISSION
     L = fma(t[k], L, e[k]);
-#else
-    L = fma(t[k], L - B[k], B[k]);
-#endif
     acc2[k] = fma(cw, L, acc2[k]);
   }
   if constexpr (DEPTH > 0) {
@@ -406,16 +375,16 @@ __device__ __forceinline__ void pair_all_angles(const Dev &d, const double (&tau
   acc1[0] = fma(d.ang[2 * na], Linit, acc1[0]);  // main.cpp:302 for all angles at once: sum_i 2*pi*mu_i*dmu * L_up
   if constexpr (!CUBE) {
     for (int n = 2 * na - 1; n >= 1; n -= 2) {
-      const double a2 = -d.ang[(n - 1) >> 1], a1 = a2 * 0x1.71547652b82fep+0;
+      const double a1 = -d.ang[(n - 1) >> 1] * 0x1.71547652b82fep+0;
       double t[NH];
 #pragma unroll
-      for (int k = 0; k < NH; ++k) t[k] = exp_trans(tau[k], a1, a2);  // main.cpp:209
+      for (int k = 0; k < NH; ++k) t[k] = exp_trans(tau[k], a1);  // main.cpp:209
       pair_chain<0>(d, t, B, Linit, n, acc1, acc2);
     }
   } else {
     const double *sched = d.ang + 2 * na + 1;
     for (int s = 0; s < d.nsched; ++s) {
-      const double a1 = sched[2 * s], a2 = a1 * 0x1.62e42fefa39efp-1;
+      const double a1 = sched[2 * s];
       const int code = (int)__double_as_longlong(sched[2 * s + 1]);
       double t[NH];
       if ((code & 3) == 2) {
@@ -423,7 +392,7 @@ __device__ __forceinline__ void pair_all_angles(const Dev &d, const double (&tau
         for (int k = 0; k < NH; ++k) t[k] = st[k][lane];
       } else {
 #pragma unroll
-        for (int k = 0; k < NH; ++k) t[k] = exp_trans(tau[k], a1, a2);  // main.cpp:209
+        for (int k = 0; k < NH; ++k) t[k] = exp_trans(tau[k], a1);  // main.cpp:209
         if (code & 1) {
 #pragma unroll
           for (int k = 0; k < NH; ++k) {

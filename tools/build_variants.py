@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Builds experimental variants of librcm_hip.so (compile-time knobs of rcm_kernels.hpp) into
 our_first_climate_model_amd/variants/ for A/B runs on the GPU:
-    python tools/build_variants.py name:-DRCM_LB=1,-DRCM_B_LDS=0 name2:...
+    python tools/build_variants.py name:-DRCM_PAIR_LB=2,-DRCM_EXP_DEG=8 name2:...
 and tools/run_variants.py times each with tools/sweep_variants.py."""
 import os
 import subprocess
