@@ -199,7 +199,10 @@ int rcm_lbl_cache_write(const char *path, int n_nodes, int nlayer, const double 
                         const double *const tabs[RCM_NSPEC_LBL]);
 int rcm_lbl_cache_read(const char *path, int *n_nodes, int *nlayer, double **wvl, double **tabs);
 
-/* .rtab blob written by tools/flatten_repwvl.py (the datasets of a Reduced*Forcing.nc file).
+/* The datasets read_tau takes from a Reduced*Forcing.nc file (repwvl_thermal.cpp:113-176), either
+ * from the file itself -- NetCDF-4 = HDF5; read without either library, for the layout netcdf-c
+ * writes (contiguous, uncompressed little-endian f64 variables; anything else: RCM_ERR_FORMAT with
+ * the feature named) -- or from the .rtab blob tools/flatten_repwvl.py makes of it (h5dump).
  * dims = {n_tpert, n_species, n_wvl, n_p}; *blob (malloc'd; rcm_free) holds p_grid, t_ref,
  * t_pert, vmrs_ref, wvl, weight, xsec back to back. */
 int rcm_rtab_load(const char *path, long long dims[4], double **blob);

@@ -11,7 +11,7 @@ LIB = os.path.join(PKG, "librcm_hip.so")
 MAIN = os.path.join(PKG, "rcm_main")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 
-SOURCES = ["rcm_capi.hip", "rcm_host.cpp"]
+SOURCES = ["rcm_capi.hip", "rcm_host.cpp", "rcm_nc.cpp"]
 HEADERS = ["rcm_kernels.hpp", "rcm_device.hpp", "rcm_internal.hpp", "rcm_exp_coef.hpp"]
 
 

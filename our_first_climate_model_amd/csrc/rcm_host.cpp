@@ -213,7 +213,7 @@ int rcm_ascii_file2xy2D(const char *path, int *nx, int *ny, double **x, double *
 }
 
 // ---------------------------------------------------------------------------------------------
-// .rtab blob (tools/flatten_repwvl.py).
+// repwvl table: the .rtab blob (tools/flatten_repwvl.py) or the .nc file itself (rcm_nc.cpp).
 // ---------------------------------------------------------------------------------------------
 int rcm_rtab_load(const char *path, long long dims[4], double **blob) {
   if (!path || !dims || !blob) return fail(RCM_ERR_ARG, "rcm_rtab_load: bad argument");
@@ -221,6 +221,11 @@ int rcm_rtab_load(const char *path, long long dims[4], double **blob) {
   if (!f) return fail(RCM_ERR_IO, std::string("rcm_rtab_load: cannot open ") + path);
   char magic[8];
   long long d[4];
+  if (std::fread(magic, 1, 8, f) == 8 && std::memcmp(magic, "\x89HDF\r\n\x1a\n", 8) == 0) {
+    std::fclose(f);  // a Reduced*Forcing.nc itself (NetCDF-4 = HDF5), as the reference opens it
+    return rcm::nc_table_load(path, dims, blob);
+  }
+  std::rewind(f);
   if (std::fread(magic, 1, 8, f) != 8 || std::memcmp(magic, "RWVLTAB1", 8) != 0 ||
       std::fread(d, sizeof(long long), 4, f) != 4 || d[0] < 2 || d[1] < 1 || d[2] < 1 || d[3] < 2 ||
       d[0] > 4096 || d[1] > 4096 || d[2] > (1 << 24) || d[3] > 4096) {

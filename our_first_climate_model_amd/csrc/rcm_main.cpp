@@ -8,7 +8,7 @@
 // reference's value as the default.  The loop body runs on the GPU (rcm_step); with --ncol N the
 // column is replicated into a CO2 sweep and column 0.. are integrated together.
 //
-//   rcm_main [--atm F] [--table F.rtab | --lbl-dir D [--lbl-cache F]] [--steps N] [--output-steps K]
+//   rcm_main [--atm F] [--table F.nc|F.rtab | --lbl-dir D [--lbl-cache F]] [--steps N] [--output-steps K]
 //            [--co2-factor X] [--ncol N] [--tsfc T] [--tau-s X] [--output F] [--device I | --devices a,b,..]
 //            [--print-cols a,b,..] [--equilibrium TOL_K] [--restart F] [--checkpoint F] [--gather-out F]
 // --devices: the ensemble is cut into contiguous blocks of ceil(ncol/n) columns, one handle per listed
@@ -41,7 +41,7 @@ namespace {
 
 struct Options {
   std::string atm = "./repwvl_V2.01_cpp/test.atm";                // main.cpp:397
-  std::string table = "./repwvl_V2.01_cpp/Reduced100Forcing.rtab"; // main.cpp:500 (flattened .nc)
+  std::string table = "./repwvl_V2.01_cpp/Reduced100Forcing.nc";   // main.cpp:500 (or a flattened .rtab)
   std::string lbl_dir, lbl_cache, restart, checkpoint, gather_out;
   std::vector<int> devices;  // empty: the single --device, no gather
   std::vector<int> print_cols = {0};

@@ -282,6 +282,10 @@ def test_driver_writes_reference_output_txt(pkg, olib, golden, tmp_path):
     _run_driver(["--atm", os.path.join(golden, "test.atm"), "--table", os.path.join(golden, "Reduced10Forcing.rtab"),
                  "--steps", "0"], tmp_path)
     assert len((tmp_path / "output.txt").read_text().splitlines()) == 67 + 7 + 20
+    # the NetCDF-4 file itself, as the reference opens it (main.cpp:500), instead of the flattened blob
+    _run_driver(["--atm", os.path.join(golden, "test.atm"), "--table", os.path.join(golden, "Reduced10Forcing.nc"),
+                 "--steps", "20", "--output-steps", "10", "--output", "nc.txt"], tmp_path)
+    assert (tmp_path / "nc.txt").read_text().splitlines() == got
 
 
 def test_driver_lbl_directory(pkg, olib, golden, tmp_path):

@@ -340,3 +340,52 @@ def test_host_abi_error_behaviour(rcm, golden, tmp_path):
     assert L.rcm_column_init(21, None, 1.0, 1.0, None, None, None, None, None, None) == -1
     assert L.rcm_destroy(None) == -1 and L.rcm_step(None, 1) == -1 and L.rcm_sync(None) == -1
     assert L.rcm_last_error().decode() != ""
+
+
+REF_NC_DIR = "/root/reference/repwvl_V2.01_cpp"  # only in the build container; never needed on the GPU box
+
+
+@pytest.mark.parametrize("table", ["Reduced10", "Reduced20", "Reduced100"])
+def test_native_nc_reader_equals_the_h5dump_blob(rcm, golden, table):
+    """rcm_rtab_load on the NetCDF-4 file itself (rcm_nc.cpp: superblock, object headers, the root group's
+    link heap, contiguous f64 datasets) == the .rtab blob made from the same file with h5dump
+    (tools/flatten_repwvl.py), bit for bit.  Reduced10Forcing.nc is committed as a fixture (a data file of
+    the reference); the two larger ones are read from the reference tree when it is there."""
+    nc = os.path.join(golden, f"{table}Forcing.nc")
+    if not os.path.exists(nc):
+        nc = os.path.join(REF_NC_DIR, f"{table}Forcing.nc")
+        if not os.path.exists(nc):
+            pytest.skip("reference tree not present")
+    a, b = rcm.read_rtab(nc), rcm.read_rtab(os.path.join(golden, f"{table}Forcing.rtab"))
+    assert sorted(a) == sorted(b)
+    for k in a:
+        if isinstance(a[k], np.ndarray):
+            assert a[k].shape == b[k].shape and np.array_equal(a[k], b[k]), k
+        else:
+            assert a[k] == b[k], k
+
+
+def test_native_nc_reader_refuses_what_it_does_not_read(rcm, golden, tmp_path):
+    raw = bytearray(open(os.path.join(golden, "Reduced10Forcing.nc"), "rb").read())
+    cases = {}
+    t = bytearray(raw)
+    i = t.find(b"\x04xsec\xb4")  # link message in the heap: name length 4, "xsec", object header address
+    assert i > 0
+    t[i + 1:i + 5] = b"xsex"
+    cases["variable xsec not found"] = bytes(t)
+    cases["fractal heap header not found"] = bytes(raw[:200000])  # the link heap is cut off
+    cases["past the end"] = bytes(raw[:len(raw) - 2000])                # ... or only the tail of a dataset
+    t = bytearray(raw)
+    t[8] = 9
+    cases["superblock version 9"] = bytes(t)
+    t = bytearray(raw)
+    j = int.from_bytes(raw[i + 5:i + 13], "little")  # object header of xsec: break its signature
+    assert t[j:j + 4] == b"OHDR"
+    t[j:j + 4] = b"XHDR"
+    cases["object header"] = bytes(t)
+    for what, blob in cases.items():
+        p = tmp_path / "t.nc"
+        p.write_bytes(blob)
+        with pytest.raises(rcm.RcmError) as e:
+            rcm.read_rtab(str(p))
+        assert e.value.code == -6 and what in str(e.value) and "flatten_repwvl.py" in str(e.value), (what, str(e.value))

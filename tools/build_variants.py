@@ -21,6 +21,7 @@ def build(spec):
     cmd = ["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "-fPIC", "--offload-arch=gfx950", "-DRCM_EXPERIMENT",
            "-I" + os.path.join(ROOT, "include"), "-I" + os.path.join(PKG, "csrc"), "-shared", "-o", so,
            os.path.join(PKG, "csrc", "rcm_capi.hip"), os.path.join(PKG, "csrc", "rcm_host.cpp"),
+           os.path.join(PKG, "csrc", "rcm_nc.cpp"),
            "-Rpass-analysis=kernel-resource-usage"] + flags
     r = subprocess.run(cmd, capture_output=True, text=True)
     if r.returncode != 0:
