@@ -199,7 +199,7 @@ void launch_rt(rcm_ensemble *h, int blocks) {
 int launch_step(rcm_ensemble *h) {
   Dev &d = h->d;
   const int first = (h->step_index == 0) ? 1 : 0;
-  hipLaunchKernelGGL(rcm::k_pre, dim3((h->ncol + 127) / 128), dim3(128), 0, h->stream, d, first);
+  hipLaunchKernelGGL(rcm::k_pre, dim3((h->ncol + rcm::WPB - 1) / rcm::WPB), dim3(64 * rcm::WPB), 0, h->stream, d, first);
   const int blocks = (int)(((long)h->ncol * d.nchunk + rcm::WPB - 1) / rcm::WPB);
   hipEvent_t e0 = nullptr, e1 = nullptr;
   if (h->timing) {

@@ -833,38 +833,53 @@ __device__ __forceinline__ void adjust(const double *conv, double (&T)[NL], doub
   for (int i = 0; i < NL; ++i) T[i] = th[i] / conv[i];
 }
 
-// One thread per column.  Start of loop iteration i (main.cpp:536-572) up to the optical-depth
-// inputs: adjustment, and for i != 0 the water-vapour feedback (main.cpp:281-289).
-__global__ void k_pre(Dev d, int first) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= d.ncol) return;
-  double T[NL], th[NL];
-#pragma unroll
-  for (int i = 0; i < NL; ++i) T[i] = d.T[(size_t)c * NL + i];
-  if (first) {  // main.cpp:500: the first optical depths come from the pre-adjustment profile
-#pragma unroll
-    for (int i = 0; i < NL; ++i) d.Ttau[(size_t)c * NL + i] = T[i];
+// One wave per column, lane l = layer l.  Start of loop iteration i (main.cpp:536-572) up to the
+// optical-depth inputs: adjustment, and for i != 0 the water-vapour feedback (main.cpp:281-289).
+// The sort of the 20 potential temperatures (main.cpp:538, descending) is a rank sort across the lanes:
+// the sorted array of a set of numbers is unique, so it is the array std::sort leaves.  A thread per
+// column (3 000 dependent instructions) took 10 us for ONE column and 18 us for 10 000.
+__global__ __launch_bounds__(64 * WPB) void k_pre(Dev d, int first) {
+  __shared__ double s_th[WPB][NL], s_sorted[WPB][NL];
+  const int lane = threadIdx.x & 63, wib = threadIdx.x >> 6;
+  const int c = blockIdx.x * WPB + wib;
+  const bool on = c < d.ncol && lane < NL;
+  const size_t at = (size_t)(on ? c : 0) * NL + (on ? lane : 0);
+  double T = 0.0, th = 0.0, conv = 1.0;
+  if (on) {
+    T = d.T[at];
+    conv = d.conv[lane];
+    if (first) d.Ttau[at] = T;  // main.cpp:500: the first optical depths come from the pre-adjustment profile
+    th = T * conv;              // t_to_theta, main.cpp:123-129
+    s_th[wib][lane] = th;
   }
-  adjust(d.conv, T, th);
-  double resid = 0.0;
-#pragma unroll
-  for (int i = 0; i < NL; ++i) {
-    d.T[(size_t)c * NL + i] = T[i];
-    resid = fmax(resid, fabs(T[i] - d.Tprev[(size_t)c * NL + i]));
-    d.Tprev[(size_t)c * NL + i] = T[i];
-  }
-  d.resid[c] = first ? 1e300 : resid;
-  if (!first) {
-    double *gas = d.gas + (size_t)c * d.ngas * NL;
-#pragma unroll
-    for (int i = 0; i < NL; ++i) {
-      d.Ttau[(size_t)c * NL + i] = T[i];
-      const double vmr = d.rel_hum[(size_t)c * NL + i] * magnus_dev(T[i]) / d.player[i];  // main.cpp:285-286
-      if (d.mode == MODE_REPWVL)
-        gas[0 * NL + i] = vmr;                 // H2O is read_tau's first species
-      else
-        gas[1 * NL + i] = vmr / d.h2o_ref[i];  // lbl: tau_H2O is linear in the mixing ratio
+  __syncthreads();
+  if (on) {
+    int rank = 0;
+    for (int j = 0; j < NL; ++j) {
+      const double tj = s_th[wib][j];
+      rank += (tj > th) || (tj == th && j < lane);
     }
+    s_sorted[wib][rank] = th;
+  }
+  __syncthreads();
+  double r = 0.0;
+  if (on) {
+    T = s_sorted[wib][lane] / conv;  // theta_to_t, main.cpp:131-139
+    d.T[at] = T;
+    r = fabs(T - d.Tprev[at]);
+    d.Tprev[at] = T;
+  }
+#pragma unroll
+  for (int off = 16; off >= 1; off >>= 1) r = fmax(r, __shfl_xor(r, off, 64));  // lanes 0..31 cover the 20 layers
+  if (on && lane == 0) d.resid[c] = first ? 1e300 : r;
+  if (on && !first) {
+    d.Ttau[at] = T;
+    const double vmr = d.rel_hum[at] * magnus_dev(T) / d.player[lane];  // main.cpp:285-286
+    double *gas = d.gas + (size_t)c * d.ngas * NL;
+    if (d.mode == MODE_REPWVL)
+      gas[0 * NL + lane] = vmr;                    // H2O is read_tau's first species
+    else
+      gas[1 * NL + lane] = vmr / d.h2o_ref[lane];  // lbl: tau_H2O is linear in the mixing ratio
   }
 }
 
@@ -880,7 +895,13 @@ __global__ __launch_bounds__(1024) void k_post(Dev d) {
   if (j < PSTRIDE) {
     const double *p = d.partial + (size_t)c * d.nchunk * PSTRIDE + j;
     double acc = 0.0;
-    for (int k = q; k < d.nchunk; k += P) acc += p[(size_t)k * PSTRIDE];
+    for (int k = q; k < d.nchunk; k += 16 * P) {  // sixteen loads in flight, added in chunk order as before
+      double v[16];
+#pragma unroll
+      for (int u = 0; u < 16; ++u) v[u] = (k + u * P < d.nchunk) ? p[(size_t)(k + u * P) * PSTRIDE] : 0.0;
+#pragma unroll
+      for (int u = 0; u < 16; ++u) acc += v[u];
+    }
     s_part[q][j] = acc;
   }
   __syncthreads();
@@ -894,29 +915,32 @@ __global__ __launch_bounds__(1024) void k_post(Dev d) {
       d.E_up[(size_t)c * NLEV + (j - NLEV)] = acc;
   }
   __syncthreads();
-  if (threadIdx.x != 0) return;
+  // dE, time step and temperature update: lane l of the first wave = layer l
+  __shared__ double s_dE[NL];
+  const int l = threadIdx.x;
   const double *Ed = s_E, *Eu = s_E + NLEV;
-  double dE[NL];
+  double dEl = 0.0;
+  if (l < NL) {
+    dEl = Ed[l] - Ed[l + 1] + Eu[l + 1] - Eu[l];                    // main.cpp:338
+    if (l == NL - 1) dEl += d.solar_irr[c] + Ed[NL] - Eu[NL];        // main.cpp:341
+    s_dE[l] = dEl;
+  }
+  __syncthreads();
+  if (l >= NL) return;
+  double mx = s_dE[0];
 #pragma unroll
-  for (int i = 0; i < NL; ++i) dE[i] = Ed[i] - Ed[i + 1] + Eu[i + 1] - Eu[i];  // main.cpp:338
-  dE[NL - 1] += d.solar_irr[c] + Ed[NL] - Eu[NL];                               // main.cpp:341
-  double mx = dE[0];
-#pragma unroll
-  for (int i = 1; i < NL; ++i) mx = (mx < dE[i]) ? dE[i] : mx;  // signed max_element, main.cpp:157
+  for (int i = 1; i < NL; ++i) mx = (mx < s_dE[i]) ? s_dE[i] : mx;  // signed max_element, main.cpp:157
   const double heat_cap = 1004.0 * d.dp * 100.0;               // c_air * dp * 100, main.cpp:157,169
   double dt = 5.0 / mx * heat_cap / 9.80665;                   // max_dT = 5 (float), main.cpp:82
   if (dt > 3600 * 12) dt = 3600 * 12;                          // main.cpp:158-160
-  double Tlast = 0.0;
-#pragma unroll
-  for (int i = 0; i < NL; ++i) {
-    const double Tn = d.T[(size_t)c * NL + i] + dE[i] * dt * 9.80665 / heat_cap;  // main.cpp:169
-    d.T[(size_t)c * NL + i] = Tn;
-    d.dE[(size_t)c * NL + i] = dE[i];
-    Tlast = Tn;
+  const double Tn = d.T[(size_t)c * NL + l] + dEl * dt * 9.80665 / heat_cap;  // main.cpp:169
+  d.T[(size_t)c * NL + l] = Tn;
+  d.dE[(size_t)c * NL + l] = dEl;
+  if (l == NL - 1) d.Tsfc[c] = Tn * d.conv[NL - 1];            // main.cpp:173
+  if (l == 0) {
+    d.dt[c] = dt;
+    d.time_h[c] += (float)dt / 3600;                           // main.cpp:581
   }
-  d.Tsfc[c] = Tlast * d.conv[NL - 1];          // main.cpp:173
-  d.dt[c] = dt;
-  d.time_h[c] += (float)dt / 3600;             // main.cpp:581
 }
 
 // output_conv view of one column (main.cpp:536-546) into scratch: adjusted T, sorted theta.
