@@ -51,6 +51,16 @@ def run(ncases=120, seed=1, log=print):
             chunks = int(rng.integers(1, max(2, (nspec + 31) // 32 + 1)))
             g.set_spectral_chunks(chunks)
         o = H.oracle_ensemble(olib, inp, nangle=nangle)
+        percol = rng.random() < 0.3
+        if percol:  # per-column forcing: solar heating, cloud layer (-1: none) and optical depth
+            sol = inp["solar"] * rng.uniform(0.8, 1.2, ncol)
+            cl = rng.integers(-1, 20, ncol).astype(np.int32)
+            ct = rng.choice([0.0, 0.5, 1.0, 8.0], ncol)
+            g.set_column_forcing(sol, cl, ct), o.set_column_forcing(sol, cl, ct)
+        split = steps > 1 and rng.random() < 0.3
+        if split:  # the same iterations in two calls
+            g.step(1), o.step(1)
+            steps -= 1
         g.step(steps), o.step(steps)
         fg, fo = g.get_fluxes(), o.get_fluxes()
         e_flux = max(H.max_abs(fg[k], fo[k]) for k in fg)
@@ -64,7 +74,7 @@ def run(ncases=120, seed=1, log=print):
         bad += not ok
         worst["flux"], worst["T"], worst["tau"] = max(worst["flux"], e_flux), max(worst["T"], e_T), max(worst["tau"], e_tau)
         log(f"{case:4d} {mode:6s} ncol={ncol:4d} nspec={nspec:5d} nangle={nangle:2d} chunks={chunks or 'auto':>5} "
-            f"used={g.get_spectral_chunks():4d} cloud=({inp['cloud_layer']:2d},{inp['cloud_tau']:4.1f}) steps={steps} "
+            f"used={g.get_spectral_chunks():4d} cloud=({inp['cloud_layer']:2d},{inp['cloud_tau']:4.1f}){'*' if percol else ' '} steps={steps}{'+1' if split else '  '} "
             f"dFlux={e_flux:.2e} dT={e_T:.2e} dtau={e_tau:.1e} time={'==' if same_time else '!='} {'ok' if ok else 'FAIL'}")
         g.close()
     log(f"{ncases} cases in {time.time() - t_start:.0f} s: {bad} outside tolerance; worst dFlux {worst['flux']:.2e} W/m^2, "
