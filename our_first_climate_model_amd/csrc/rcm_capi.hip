@@ -46,6 +46,7 @@ struct rcm_ensemble {
   Dev d{};
   double *scratch = nullptr;  // 2*NL doubles
   double *partial_buf = nullptr;
+  double *slice_buf = nullptr;  // [ncol][kPostSlices][42]: first stage of the chunk sum for few columns x many chunks
   // repwvl host copies needed to (re)derive per-layer constants
   std::vector<double> p_grid;
   int *d_ip = nullptr;
@@ -145,6 +146,8 @@ void choose_chunks(int ncol, int nspec, int user_chunks, int *nchunk_out, int *c
 
 // repwvl with the (column, wavelength) pairs flattened over the lane pairs (k_rt_repwvl_flat): the
 // production path unless the caller pins a chunk count or selects a reference variant.
+constexpr int kPostSlices = 32;  // blocks per column of the first-stage chunk sum (k_reduce_partials)
+
 bool use_flat(const rcm_ensemble *h) {
   return h->mode == rcm::MODE_REPWVL && h->flat && h->pair && h->exp_variant == 1 && h->user_chunks == 0 &&
          h->d.n_wvl >= 8;  // at most 31/8 + 2 = 5 column images per wave
@@ -166,6 +169,12 @@ int ensure_partials(rcm_ensemble *h) {
   HIPCK(hipMalloc((void **)&h->partial_buf, bytes));
   HIPCK(hipMemsetAsync(h->partial_buf, 0, bytes, h->stream));  // slots a column never writes must read as 0
   h->d.partial = h->partial_buf;
+  if (h->slice_buf) {
+    HIPCK(hipFree(h->slice_buf));
+    h->slice_buf = nullptr;
+  }
+  if (h->d.nchunk >= 512 && h->ncol <= 64)  // measured: one column x 2 048 records, k_post 18 -> 3 + 5 us
+    HIPCK(hipMalloc((void **)&h->slice_buf, (size_t)h->ncol * kPostSlices * rcm::PSTRIDE * sizeof(double)));
   return RCM_OK;
 }
 
@@ -230,9 +239,17 @@ int launch_step(rcm_ensemble *h) {
     launch_rt<1, 1>(h, blocks);
 #endif
   if (h->timing) HIPCK(hipEventRecord(e1, h->stream));
-  int post_waves = d.nchunk / 16;  // waves per column in k_post: one per 16 chunk partials, 1..16
+  Dev dp = d;  // what k_post sums: the chunk records, or their slice sums
+  if (h->slice_buf) {
+    const int len = (d.nchunk + kPostSlices - 1) / kPostSlices;
+    hipLaunchKernelGGL(rcm::k_reduce_partials, dim3(kPostSlices, h->ncol), dim3(64 * 8), 0, h->stream, d.partial,
+                       h->slice_buf, d.nchunk, len, kPostSlices);
+    dp.partial = h->slice_buf;
+    dp.nchunk = kPostSlices;
+  }
+  int post_waves = dp.nchunk / 16;  // waves per column in k_post: one per 16 chunk partials, 1..16
   post_waves = post_waves < 1 ? 1 : (post_waves > 16 ? 16 : post_waves);
-  hipLaunchKernelGGL(rcm::k_post, dim3(h->ncol), dim3(64 * post_waves), 0, h->stream, d);
+  hipLaunchKernelGGL(rcm::k_post, dim3(h->ncol), dim3(64 * post_waves), 0, h->stream, dp);
   HIPCK(hipGetLastError());
   ++h->step_index;
   return RCM_OK;
@@ -378,6 +395,7 @@ int rcm_destroy(rcm_ensemble *h) {
   if (h->stream) (void)hipStreamSynchronize(h->stream);
   for (void *p : h->allocs) (void)hipFree(p);
   if (h->partial_buf) (void)hipFree(h->partial_buf);
+  if (h->slice_buf) (void)hipFree(h->slice_buf);
   for (auto &ev : h->events) {
     (void)hipEventDestroy(ev.first);
     (void)hipEventDestroy(ev.second);

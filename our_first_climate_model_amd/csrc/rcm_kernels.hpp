@@ -883,6 +883,36 @@ __global__ __launch_bounds__(64 * WPB) void k_pre(Dev d, int first) {
   }
 }
 
+// First stage of the chunk sum for FEW columns with MANY chunk records (one column x the full lbl
+// spectrum: 2 048 records): one block of k_post pulls them through a single CU (18 us).  Block (slice,
+// column) sums the records [slice*len, (slice+1)*len) in chunk order into out[column][slice][42]; k_post
+// then sums the slices.  Fixed order, so still deterministic for a given chunking.
+__global__ __launch_bounds__(1024) void k_reduce_partials(const double *partial, double *out, int nchunk, int len,
+                                                          int nslice) {
+  __shared__ double s_part[16][PSTRIDE];
+  const int slice = blockIdx.x, c = blockIdx.y;
+  const int j = threadIdx.x & 63, q = threadIdx.x >> 6, P = blockDim.x >> 6;
+  const int k0 = slice * len, k1 = min(k0 + len, nchunk);
+  if (j < PSTRIDE) {
+    const double *p = partial + (size_t)c * nchunk * PSTRIDE + j;
+    double acc = 0.0;
+    for (int k = k0 + q; k < k1; k += 8 * P) {
+      double v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = (k + u * P < k1) ? p[(size_t)(k + u * P) * PSTRIDE] : 0.0;
+#pragma unroll
+      for (int u = 0; u < 8; ++u) acc += v[u];
+    }
+    s_part[q][j] = acc;
+  }
+  __syncthreads();
+  if (q == 0 && j < PSTRIDE) {
+    double acc = s_part[0][j];
+    for (int r = 1; r < P; ++r) acc += s_part[r][j];
+    out[((size_t)c * nslice + slice) * PSTRIDE + j] = acc;
+  }
+}
+
 // One block of P waves per column (P = blockDim.x/64 <= 16).  Wave q sums the chunk partials
 // q, q+P, q+2P, .. in that order, the P sums are combined in wave order (deterministic for a given
 // chunking), then lane 0 runs the tail of radiative_transfer (main.cpp:337-341), calculate_timestep
