@@ -76,7 +76,28 @@ Options parse(int argc, char **argv) {
       }
       return argv[++i];
     };
-    if (a == "--atm") o.atm = val();
+    if (a == "--help" || a == "-h") {
+      std::printf(
+          "rcm_main: the reference's main() (main.cpp:353-596) on the MI355X library.\n"
+          "  --atm F            atmosphere file (default ./repwvl_V2.01_cpp/test.atm)\n"
+          "  --table F          repwvl table, Reduced*Forcing.nc or its .rtab blob (default ./repwvl_V2.01_cpp/Reduced100Forcing.nc)\n"
+          "  --lbl-dir D        line-by-line path: D/lbl.{co2,h2o,o3,ch4,n2o}.asc (lbl.arts/README)\n"
+          "  --lbl-cache F      binary cache of the five tables: read if present, else written\n"
+          "  --steps N          Consts::n_steps (1): iterations i = 0..N inclusive\n"
+          "  --output-steps K   Consts::output_steps (10)\n"
+          "  --co2-factor X     CO2 multiplier (main.cpp:452)\n"
+          "  --tsfc T           initial surface temperature (288.2)\n"
+          "  --tau-s X          optical thickness of the cloud in the solar set-up (2.0)\n"
+          "  --ncol N           ensemble: CO2 factor x linspace(0.5, 4) over N columns\n"
+          "  --print-cols a,b   columns whose profile block is written at every output time (0)\n"
+          "  --equilibrium TOL  stop when the adjusted profile changes by <= TOL K per step in every column\n"
+          "  --restart F / --checkpoint F   binary restart file\n"
+          "  --device I | --devices a,b,..  one GPU, or one handle per listed GPU and one RCCL all-gather\n"
+          "  --gather-out F     the gathered state: col,T_surface,Tlayer[0..19] per line\n"
+          "  --output F         output.txt (appended, reference formats)\n");
+      std::exit(0);
+    }
+    else if (a == "--atm") o.atm = val();
     else if (a == "--table") o.table = val();
     else if (a == "--lbl-dir") o.lbl_dir = val();
     else if (a == "--output") o.output = val();
