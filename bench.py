@@ -46,7 +46,7 @@ def cpu_baseline(pkg, inp_full, n_nodes, log):
     import oracle_lib as ol
     olib = ol.load()
     cores = host_cores()
-    ncol = 6 * cores  # ~13 s of CPU work on the 16 threads of a one-GPU box
+    ncol = min(6 * cores, inp_full["ncol"])  # ~13 s of CPU work on the 16 threads of a one-GPU box
     inp = dict(inp_full)
     inp["ncol"] = ncol
     inp["cols"] = {k: (v[:ncol] if getattr(v, "ndim", 0) >= 1 and v.shape[0] == inp_full["ncol"] else v)
@@ -84,6 +84,12 @@ def main():
     ap.add_argument("--backend", default="nccl", choices=("nccl", "gloo"),
                     help="torch.distributed backend; gloo only to rehearse the N>1 path on a one-GPU box")
     args = ap.parse_args()
+
+    # stdout carries exactly ONE line, the JSON: libraries that print banners to fd 1 (RCCL does when its
+    # communicator comes up) are sent to stderr until the result is ready
+    sys.stdout.flush()
+    stdout_fd = os.dup(1)
+    os.dup2(2, 1)
 
     import numpy as np
     import torch
@@ -204,7 +210,10 @@ def main():
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"], oe = cpu_baseline(pkg, inp, args.nodes, log)
+        sys.stdout.flush()
+        os.dup2(stdout_fd, 1)
         print(json.dumps(out), flush=True)
+        os.dup2(2, 1)
     if use_dist:
         dist.barrier()
         dist.destroy_process_group()

@@ -534,8 +534,8 @@ def test_bench_contract_on_a_small_workload(pkg):
     r = subprocess.run([sys.executable, os.path.join(H.ROOT, "bench.py"), "--ncol", "64", "--nodes", "4097", "--steps",
                         "2", "--warmup", "1"], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-2000:]
-    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
-    assert len(lines) == 1
+    lines = r.stdout.splitlines()
+    assert len(lines) == 1, r.stdout  # exactly ONE line on stdout, the JSON (banners and logs go to stderr)
     d = json.loads(lines[0])
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
               "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
