@@ -77,7 +77,8 @@ int rcm_solar_setup_columns(rcm_ensemble *h, const double *tau_s, const double *
 
 /* Replaces the table side of read_tau (repwvl_thermal.cpp:113-176): the datasets of a
  * Reduced*Forcing.nc file, xsec in FILE order [n_tpert][n_species][n_wvl][n_p].  The library
- * re-lays it out wavelength-fastest on the device.  n_species must be 9. */
+ * re-lays it out wavelength-fastest on the device.  n_species must be 9; the table must stay
+ * below 4 GiB (the shipped ones: 0.3 - 2.7 MB). */
 int rcm_set_repwvl_tables(rcm_ensemble *h, int n_tpert, int n_species, int n_wvl, int n_p,
                           const double *p_grid, const double *t_ref, const double *t_pert,
                           const double *wvl, const double *weight, const double *xsec);
@@ -87,7 +88,8 @@ int rcm_set_repwvl_tables(rcm_ensemble *h, int n_tpert, int n_species, int n_wvl
  * optical depths exactly as ASCII_file2xy2D returns them, s in RCM_NSPEC_LBL order; h2o_ref
  * [nlayer] = the H2O mixing ratio the H2O table was computed at (absolute).  Spectral band b
  * (0 <= b < n_nodes-1) spans wvl[b]..wvl[b+1], takes node b's optical depth and the
- * band-integrated Planck source cplkavg(wvl[b], wvl[b+1], T) (cplkavg.cpp:124-243). */
+ * band-integrated Planck source cplkavg(wvl[b], wvl[b+1], T) (cplkavg.cpp:124-243).  The five
+ * tables together must stay below 4 GiB (n_nodes < 5.3 million). */
 int rcm_set_lbl_tables(rcm_ensemble *h, int n_nodes, const double *wvl,
                        const double *const tabs[RCM_NSPEC_LBL], const double *h2o_ref);
 
