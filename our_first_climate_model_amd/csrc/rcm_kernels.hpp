@@ -572,11 +572,14 @@ __global__ __launch_bounds__(64 * WPB, RCM_PAIR_LB) void k_rt_lbl_pair(Dev d) {
 struct RepwvlPairLds {
   double T[2][NH + 1];   // T[p][k] = Tlayer[layer(p,k)], k = NH: T_surface
   double rT[2][NH + 1];  // 1/T
-  double delT[2][NH], delP[2][NH], numDens[2][NH];
+  // numDens (:246) times the four bilinear weights of the layer's (T, p) bracket: corners (it, ip),
+  // (it+1, ip), (it, ip+1), (it+1, ip+1).  The reference forms c0 + cT*delT + cP*delP + cPT*delT*delP from
+  // corner DIFFERENCES (:235-241); the weighted sum of the corners is the same number up to rounding
+  // (rcm_get_tau, k_tau, keeps the reference's form) for 5 instead of 11 instructions per species and layer.
+  double w[2][NH][4];
   double vmr[2][RCM_NSPEC_REPWVL][NH];
-  double cloud_tau;
+  double cloud[2][NH];   // grey cloud optical depth of the layer (main.cpp:266-274), 0 elsewhere
   unsigned xoff[2][NH];  // byte offset of xsec[it][0][ip][0]: the (T, p) bracket of the layer (:229-232)
-  int cloud_k[2];        // position of the cloud layer in the lane's ordering (outside [0, NH): none)
 };
 
 // Fills the LDS image of column `col`: per (parity, position) the temperature bracket of read_tau
@@ -598,16 +601,12 @@ __device__ __forceinline__ void repwvl_pair_image(const Dev &d, int col, int lan
       const int it = lower_pos_dev([&](int j) { return tr + tp[j]; }, d.n_tpert, midT);  // :229-232
       const double t0 = tr + tp[it], t1 = tr + tp[it + 1];
       s.xoff[q][k] = (unsigned)(((size_t)it * d.n_species * d.n_p + ip) * d.n_wvl * sizeof(double));
-      s.delT[q][k] = (midT - t0) / (t1 - t0);  // :239
-      s.delP[q][k] = d.delP[layer];
-      s.numDens[q][k] = d.numDens[layer];
+      const double dT = (midT - t0) / (t1 - t0);  // :239
+      const double dP = d.delP[layer], nd = d.numDens[layer];
+      const double w11 = dT * dP, w10 = dT - w11, w01 = dP - w11, w00 = (1.0 - dT) - w01;
+      s.w[q][k][0] = nd * w00, s.w[q][k][1] = nd * w10, s.w[q][k][2] = nd * w01, s.w[q][k][3] = nd * w11;
+      s.cloud[q][k] = (layer == d.cloud_layer[col]) ? d.cloud_tau[col] : 0.0;
     }
-  }
-  if (lane == 32) {
-    const int cl = d.cloud_layer[col];
-    s.cloud_k[0] = cl;
-    s.cloud_k[1] = NL - 1 - cl;
-    s.cloud_tau = d.cloud_tau[col];
   }
   for (int i = lane; i < 2 * RCM_NSPEC_REPWVL * NH; i += 64) {
     const int q = i / (RCM_NSPEC_REPWVL * NH), r = i - q * (RCM_NSPEC_REPWVL * NH);
@@ -628,28 +627,22 @@ __device__ __forceinline__ void repwvl_pair_point(const Dev &d, const RepwvlPair
   const unsigned ld8 = (unsigned)d.n_wvl * 8u, sp8 = (unsigned)d.n_p * ld8;
   const char *b00 = (const char *)d.xsec, *b01 = b00 + ld8;
   const char *b10 = b00 + (size_t)d.n_species * sp8, *b11 = b10 + ld8;
-  const int cloud_k = s.cloud_k[p];
-  const double cloud_tau = s.cloud_tau;
   double tau[NH];
 #pragma unroll 1
   for (int k = 0; k < NH; ++k) {
     const unsigned vo = s.xoff[p][k] + (unsigned)w * 8u;
-    const double delT = s.delT[p][k], delP = s.delP[p][k];
+    const double w00 = s.w[p][k][0], w10 = s.w[p][k][1], w01 = s.w[p][k][2], w11 = s.w[p][k][3];
     double a = 0.0;
 #pragma unroll
     for (int sp = 0; sp < RCM_NSPEC_REPWVL; ++sp) {
       if (!((d.species_mask >> sp) & 1u)) continue;  // vmr == 0 everywhere: the term is +0
       const unsigned v = vo + (unsigned)sp * sp8;
-      const double c0 = *(const double *)(b00 + v);                   // :235
-      const double cT = *(const double *)(b10 + v) - c0;              // :236
-      const double cP = *(const double *)(b01 + v) - c0;              // :237
-      const double cPT = *(const double *)(b11 + v) - cP - cT - c0;  // :238
-      const double xs = c0 + cT * delT + cP * delP + cPT * delT * delP;  // :241
-      a += xs * s.vmr[p][sp][k];                 // :244
+      const double xs = fma(w11, *(const double *)(b11 + v),
+                            fma(w01, *(const double *)(b01 + v),
+                                fma(w10, *(const double *)(b10 + v), w00 * *(const double *)(b00 + v))));
+      a = fma(xs, s.vmr[p][sp][k], a);  // :244, with numDens (:246) already in the weights
     }
-    a *= s.numDens[p][k];                        // :246
-    if (k == cloud_k) a += cloud_tau;            // main.cpp:266-274
-    st[k][lane] = clamp_tau(a);
+    st[k][lane] = clamp_tau(a + s.cloud[p][k]);  // main.cpp:266-274; + 0.0 leaves the other layers as they are
   }
 #pragma unroll
   for (int k = 0; k < NH; ++k) tau[k] = st[k][lane];
