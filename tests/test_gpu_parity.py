@@ -286,6 +286,16 @@ def test_driver_writes_reference_output_txt(pkg, olib, golden, tmp_path):
     _run_driver(["--atm", os.path.join(golden, "test.atm"), "--table", os.path.join(golden, "Reduced10Forcing.nc"),
                  "--steps", "20", "--output-steps", "10", "--output", "nc.txt"], tmp_path)
     assert (tmp_path / "nc.txt").read_text().splitlines() == got
+    # no arguments at all, in a directory laid out like the reference's: its compiled-in paths (main.cpp:397,500)
+    # and n_steps = 1, output_steps = 10 (main.cpp:83-84); the table behind that name is Reduced10 here
+    import shutil
+    ref_dir = tmp_path / "refdir"
+    (ref_dir / "repwvl_V2.01_cpp").mkdir(parents=True)
+    shutil.copy(os.path.join(golden, "test.atm"), ref_dir / "repwvl_V2.01_cpp" / "test.atm")
+    shutil.copy(os.path.join(golden, "Reduced10Forcing.nc"), ref_dir / "repwvl_V2.01_cpp" / "Reduced100Forcing.nc")
+    _run_driver([], ref_dir)
+    plain = (ref_dir / "output.txt").read_text().splitlines()
+    assert plain == got[:27]  # banner + the t = 0 block, exactly what ./main appends for n_steps = 1
 
 
 def test_driver_lbl_directory(pkg, olib, golden, tmp_path):
