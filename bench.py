@@ -182,11 +182,17 @@ def main():
         achieved = alg_bytes / rt_avg_s / 1e9
         # HBM bytes per launch from the PMC passes committed under profiles/ (FETCH_SIZE x 2 + WRITE_SIZE,
         # MI355X_MICROARCH.md HBM section); only valid for the workload they were collected on
-        traffic, traffic_src = None, None
+        traffic, traffic_src, valu = None, None, None
         try:
-            prof = json.load(open(os.path.join(ROOT, "profiles", "r01_final_pmc.json")))["hbm_traffic"]
+            pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_final_pmc.json")))
+            prof = pmc["hbm_traffic"]
             if prof["algorithmic_bytes_per_launch"] == alg_bytes:
                 traffic, traffic_src = prof["traffic_bytes_per_launch"], "profiles/r01_final_pmc.json"
+            # the bound that actually holds: every wave64 VALU instruction occupies its SIMD for 4 cycles;
+            # instruction count per 64 bands from the committed PMC pass, time from this run's HIP events
+            ipb = pmc["derived"]["valu_instructions_per_64_bands"]
+            valu = {"instructions_per_64_bands": ipb, "source": "profiles/r01_final_pmc.json",
+                    "issue_frac_at_2.4GHz": ipb * (nband * ncol_local / 64.0) * 4 / (1024 * 2.4e9 * rt_avg_s)}
         except (OSError, KeyError, ValueError):
             pass
         out = {
@@ -203,7 +209,7 @@ def main():
             "roofline": {"bound": "hbm", "kernel": "k_rt_lbl_pair", "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                          "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": rt_avg_s * 1e3,
-                         "launches": rt_n,
+                         "launches": rt_n, "fp64_valu_issue": valu,
                          "note": "numerator = 808 B per (column, band), as if every column streamed the 5 species "
                                  "tables itself (SURVEY 8d); the tables are shared, real HBM traffic is ~1% of "
                                  "that and the kernel is fp64-VALU-issue bound (94% VALU busy, profiles/README.md)"},
