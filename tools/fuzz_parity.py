@@ -3,7 +3,7 @@
 count, spectral chunking, cloud position/depth and step count are drawn from a seeded generator; fluxes,
 optical depths and temperatures are compared with the CPU oracle at the tolerances of the tests.
 
-    python tools/fuzz_parity.py [cases=120] [seed=1]
+    python tools/fuzz_parity.py [cases=120] [seed=1] [big]
 
 Prints one line per case and a summary; exit code 1 if any case is outside the tolerance."""
 import os
@@ -22,7 +22,7 @@ import our_first_climate_model_amd as pkg
 FLUX_TOL, T_TOL, TAU_RTOL = 2e-9, 1e-9, 1e-12  # tests/test_gpu_parity.py
 
 
-def run(ncases=120, seed=1, log=print):
+def run(ncases=120, seed=1, log=print, big=False):
     """Returns (cases outside the tolerance, worst deviations)."""
     rng = np.random.default_rng(seed)
     olib = ol.load()
@@ -32,7 +32,13 @@ def run(ncases=120, seed=1, log=print):
     for case in range(ncases):
         mode = "lbl" if rng.random() < 0.6 else "repwvl"
         nangle = int(rng.choice([30, 30, 30, 1, 2, 3, 5, 7, 13, 29, 31, 45, 64]))
-        if mode == "lbl":
+        if mode == "lbl" and big and rng.random() < 0.5:
+            # few columns x long spectra: many chunk records per column (two-stage chunk sum, k_reduce_partials)
+            n_nodes = int(rng.integers(16000, 40000))
+            ncol = int(rng.integers(1, 6))
+            inp = H.make_inputs(pkg, "lbl", ncol, n_nodes=n_nodes, atm="fpda.lbl.atm", perturb=True)
+            nspec = n_nodes - 1
+        elif mode == "lbl":
             n_nodes = int(rng.choice([2, 3, 33, 34, 64, 65, 66, 97, 129, int(rng.integers(2, 6000))]))
             ncol = int(rng.integers(1, max(2, min(200, 150000 // max(n_nodes, 1)))))
             inp = H.make_inputs(pkg, "lbl", ncol, n_nodes=n_nodes, atm="fpda.lbl.atm", perturb=bool(rng.random() < 0.8))
@@ -83,5 +89,6 @@ def run(ncases=120, seed=1, log=print):
 
 
 if __name__ == "__main__":
-    n_bad, _ = run(int(sys.argv[1]) if len(sys.argv) > 1 else 120, int(sys.argv[2]) if len(sys.argv) > 2 else 1)
+    n_bad, _ = run(int(sys.argv[1]) if len(sys.argv) > 1 else 120, int(sys.argv[2]) if len(sys.argv) > 2 else 1,
+                   big=len(sys.argv) > 3 and sys.argv[3] == "big")
     sys.exit(1 if n_bad else 0)
