@@ -1,5 +1,6 @@
 # C++-only build of the product (no Python needed): the HIP library with its C ABI and the main() drop-in.
 #   make            -> our_first_climate_model_amd/librcm_hip.so + our_first_climate_model_amd/rcm_main
+#   make examples   -> examples/abi_minimal (the C ABI from a plain C++ program)
 #   make oracle     -> the CPU checker (test infrastructure, never linked into the product)
 # `python -m our_first_climate_model_amd.build` does the same from Python (and is what __graft_entry__.build() calls).
 HIPCC     ?= /opt/rocm/bin/hipcc
@@ -16,6 +17,11 @@ RCCL_FLAGS := $(if $(wildcard $(ROCM_PATH)/include/rccl/rccl.h),-DRCM_WITH_RCCL 
 
 all: $(LIB) $(MAIN)
 
+examples: examples/abi_minimal
+
+examples/abi_minimal: examples/abi_minimal.cpp $(LIB) include/rcm.h
+	g++ -O2 -std=c++17 -Iinclude -o $@ $< -L$(PKG) -lrcm_hip -Wl,-rpath,'$$ORIGIN/../$(PKG)'
+
 $(LIB): $(CSRC)/rcm_capi.hip $(CSRC)/rcm_host.cpp $(CSRC)/rcm_nc.cpp $(HDRS)
 	$(HIPCC) -O3 -std=c++17 -fPIC --offload-arch=gfx950 -Iinclude -I$(CSRC) -Wall -Wno-unused-function -shared -o $@ \
 	  $(CSRC)/rcm_capi.hip $(CSRC)/rcm_host.cpp $(CSRC)/rcm_nc.cpp
@@ -27,6 +33,6 @@ oracle:
 	$(MAKE) -C oracle
 
 clean:
-	rm -f $(LIB) $(MAIN)
+	rm -f $(LIB) $(MAIN) examples/abi_minimal
 
-.PHONY: all oracle clean
+.PHONY: all examples oracle clean

@@ -620,3 +620,22 @@ def test_randomised_configurations_against_oracle(pkg, olib):
     bad, worst = fuzz_parity.run(60, 20260104, lines.append)
     assert bad == 0, "\n".join(ln for ln in lines if "FAIL" in ln)
     assert worst["flux"] <= 2e-9 and worst["T"] <= 1e-9 and worst["tau"] <= 1e-12
+
+
+def test_c_abi_from_a_plain_cpp_program(pkg, golden, probe, tmp_path):
+    """examples/abi_minimal.cpp (the calls of INTEGRATION.md route B, only include/rcm.h) compiled with g++ against
+    librcm_hip.so: one column, Reduced10 read from the .nc, 101 iterations -> the T_surface the unmodified reference
+    reaches (SURVEY.md 8c probe, 299.8299191384 K)."""
+    import subprocess
+    exe = tmp_path / "abi_minimal"
+    pkgdir = os.path.join(H.ROOT, "our_first_climate_model_amd")
+    subprocess.run(["g++", "-O2", "-std=c++17", "-I" + os.path.join(H.ROOT, "include"), "-o", str(exe),
+                    os.path.join(H.ROOT, "examples", "abi_minimal.cpp"), "-L" + pkgdir, "-lrcm_hip",
+                    "-Wl,-rpath," + pkgdir], check=True)
+    r = subprocess.run([str(exe), os.path.join(golden, "test.atm"), os.path.join(golden, "Reduced10Forcing.nc"), "101"],
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr
+    last = r.stdout.strip().splitlines()[-1]
+    assert last.startswith("iteration  101")
+    tsfc = float(last.split("T_surface")[1].split()[0])
+    assert abs(tsfc - probe["Reduced10"]["after_101_steps"]["T_surface"]) < 1e-6
