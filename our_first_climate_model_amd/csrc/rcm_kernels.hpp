@@ -844,6 +844,7 @@ __global__ __launch_bounds__(64 * WPB) void k_pre(Dev d, int first) {
     if (first) d.Ttau[at] = T;  // main.cpp:500: the first optical depths come from the pre-adjustment profile
     th = T * conv;              // t_to_theta, main.cpp:123-129
     s_th[wib][lane] = th;
+    s_sorted[wib][lane] = __builtin_nan("");  // a NaN among the inputs leaves ranks unassigned: the column stays NaN
   }
   __syncthreads();
   if (on) {

@@ -639,3 +639,16 @@ def test_c_abi_from_a_plain_cpp_program(pkg, golden, probe, tmp_path):
     assert last.startswith("iteration  101")
     tsfc = float(last.split("T_surface")[1].split()[0])
     assert abs(tsfc - probe["Reduced10"]["after_101_steps"]["T_surface"]) < 1e-6
+
+
+def test_nan_column_stays_nan_and_isolated(pkg):
+    """A NaN in one column's profile must not be laundered into finite garbage (the rank sort of k_pre leaves
+    unassigned ranks NaN) and must not touch its neighbours: columns are independent."""
+    inp = H.make_inputs(pkg, "repwvl", 3, table="Reduced10")
+    inp["cols"]["Tlayer0"] = inp["cols"]["Tlayer0"].copy()
+    inp["cols"]["Tlayer0"][1, 5] = np.nan
+    g = H.gpu_ensemble(pkg, inp)
+    g.step(3)
+    s = g.get_state()
+    assert np.isfinite(s["Tlayer"][0]).all() and np.isfinite(s["Tlayer"][2]).all()
+    assert np.isnan(s["Tlayer"][1]).all() and np.isnan(s["T_surface"][1])
