@@ -26,9 +26,10 @@ __device__ __forceinline__ double clamp_tau(double tau) { return fmin(fmax(tau, 
 
 #ifndef RCM_EXP_DEG
 #define RCM_EXP_DEG 9  // degree of the 2^f polynomial of the transmissions (c0 = 1 exactly): max rel err
-                       // 10 -> 5.8e-16, 9 -> 3.7e-14 (default), 8 -> 2.1e-12.  Measured on the MI355X against
-                       // the oracle: flux deviation 1e-12..4e-11 W/m^2 for 10 and 9 alike, 3e-11..5e-11 for 8
-                       // (3.8 % faster); the contract is 1e-6 W/m^2.
+                       // 10 -> 5.8e-16, 9 -> 3.7e-14 (default), 8 -> 2.1e-12.  Flux error of the kernel against a
+                       // long-double evaluation of the reference's sweep (tools/accuracy_vs_longdouble.py, 19 999
+                       // bands): 1.6e-13, 4.3e-13, 2.0e-11 W/m^2; the CPU reference itself: 2e-11.  Degree 8 is
+                       // 2.6 % faster; the contract is 1e-6 W/m^2.
 #endif
 __device__ __forceinline__ double exp_trans(double tau, double a1) {
   constexpr double kMagic = 0x1.8p+52;
