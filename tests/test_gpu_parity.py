@@ -652,3 +652,14 @@ def test_nan_column_stays_nan_and_isolated(pkg):
     s = g.get_state()
     assert np.isfinite(s["Tlayer"][0]).all() and np.isfinite(s["Tlayer"][2]).all()
     assert np.isnan(s["Tlayer"][1]).all() and np.isnan(s["T_surface"][1])
+
+
+def test_kernel_is_closer_to_long_double_than_the_reference_arithmetic(pkg, olib):
+    """tools/accuracy_vs_longdouble.py: the reference's sweep re-evaluated in long double from the same optical
+    depths and Planck values.  The kernel stays within 5e-12 W/m2 of it and is no farther from it than the CPU
+    oracle (whose running sum over the bands carries the larger rounding error)."""
+    import sys
+    sys.path.insert(0, os.path.join(H.ROOT, "tools"))
+    import accuracy_vs_longdouble as acc
+    for eg, eo, ego in acc.run(3000, lambda *_: None):
+        assert eg <= 5e-12 and eg <= eo and ego <= 2e-9
