@@ -1,17 +1,24 @@
 #!/usr/bin/env python3
-"""Headline benchmark: column-timesteps/s of the radiative-convective column integrator on the
-10 000-column ensemble with the full (synthetic, 131 072-node) lbl.arts 5-species spectrum
-(BASELINE.json configs[3]; the real lbl.*.asc files are absent from the reference tree).
+"""Headline benchmark: column-timesteps/s of the radiative-convective column integrator.
 
-    python bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W [--workload lbl|repwvl100]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+Workloads (BASELINE.json `configs`):
+  lbl        (default, the headline) configs[3]: 10 000-column ensemble x the full lbl.arts 5-species spectrum
+             (synthetic, 131 072 nodes, seeded: the real lbl.*.asc files are absent from the reference tree)
+  repwvl100  configs[2]: 10 000-column ensemble x repwvl Reduced100Forcing (the reference's own table)
 
 One "step" = one pass of the time-loop body main.cpp:531-583 over every column of the ensemble.
 The ensemble is sharded by columns over the ranks (strong scaling: the total stays 10 000); the only
 exchange is one all-gather of (Tlayer, T_surface) after the K steps, inside the timed region.
 Prints ONE JSON line on rank 0.
+
+The product path (set-up, steps, gather) imports the package only.  The `cpu_baseline` leg -- rank 0, N = 1,
+after the timed region -- is the one place that loads the CPU oracle (tests/oracle_lib.py -> oracle/).
 """
 import argparse
+import hashlib
 import json
 import os
 import sys
@@ -19,10 +26,22 @@ import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
-sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 BYTES_PER_BAND = 5 * 20 * 8 + 8  # 5 species x 20 layers x f64 + the wavelength
+BYTES_PER_RWVL = 9 * 9 * 41 * 8 + 16  # xsec[9][9][.][41] f64 per wavelength + (lambda, weight)
+NOMINAL_CLOCK_HZ = 2.4e9
+N_SIMD = 256 * 4
+
+
+def kernel_source_id():
+    """Identifies the kernel build the committed instruction counts belong to: sha256 over the device sources.
+    tools/assemble_profiles.py stores it with the counters; a mismatch here means the counts are stale."""
+    h = hashlib.sha256()
+    for f in ("rcm_kernels.hpp", "rcm_device.hpp", "rcm_exp_coef.hpp"):
+        with open(os.path.join(ROOT, "our_first_climate_model_amd", "csrc", f), "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:16]
 
 
 def host_cores():
@@ -38,44 +57,110 @@ def host_cores():
     return n
 
 
-def cpu_baseline(pkg, inp_full, n_nodes, log):
-    """The CPU oracle (a port of the reference; main.cpp itself needs netcdf and cannot be built here)
-    timed on this host's cores on a bounded sample of the same workload."""
+def _subset(inp, n):
+    """The first n columns of an input description."""
+    out = dict(inp)
+    out["ncol"] = n
+    out["cols"] = {k: (v[:n] if getattr(v, "ndim", 0) >= 1 and v.shape[0] == inp["ncol"] else v)
+                   for k, v in inp["cols"].items()}
+    return out
+
+
+def cpu_baseline(pkg, inp_full, workload, log):
+    """The CPU oracle (a port of the reference; main.cpp itself needs netcdf and cannot be built here) timed on
+    this host's cores on a bounded sample of the same workload: all cores and one core (the reference is
+    single-threaded), full step and radiative transfer alone."""
+    import ctypes as C
     import numpy as np
-    import helpers as H
-    import oracle_lib as ol
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle_lib as ol  # noqa: E402  (test infrastructure: the checker, timed here as the CPU baseline)
     olib = ol.load()
     cores = host_cores()
-    ncol = min(6 * cores, inp_full["ncol"])  # ~13 s of CPU work on the 16 threads of a one-GPU box
-    inp = dict(inp_full)
-    inp["ncol"] = ncol
-    inp["cols"] = {k: (v[:ncol] if getattr(v, "ndim", 0) >= 1 and v.shape[0] == inp_full["ncol"] else v)
-                   for k, v in inp_full["cols"].items()}
-    e = H.oracle_ensemble(olib, inp, threads=cores)
+    lbl = inp_full["mode"] == "lbl"
+    # ~13 s of CPU work on the 16 threads of a one-GPU box
+    ncol = min((6 if lbl else 4000) * cores, inp_full["ncol"])
+    steps = 1 if lbl else 10
+
+    def ensemble(inp, threads):
+        e = ol.OracleEnsemble(olib, inp["ncol"])
+        pkg.configure(e, inp)
+        e.set_threads(threads)
+        return e
+
+    inp = _subset(inp_full, ncol)
+    e = ensemble(inp, cores)
     t0 = time.perf_counter()
-    e.step(1)
-    dt = time.perf_counter() - t0
+    e.step(steps)
+    dt = (time.perf_counter() - t0) / steps
     used = e.threads_used()
-    log(f"cpu_baseline: {ncol} columns x 1 step on {used} threads in {dt:.2f} s")
-    # the reference itself is single-threaded (SURVEY.md section 0): one column on one core as well
-    inp1 = dict(inp)
-    inp1["ncol"] = 1
-    inp1["cols"] = {k: (v[:1] if getattr(v, "ndim", 0) >= 1 and v.shape[0] == ncol else v) for k, v in inp["cols"].items()}
-    e1 = H.oracle_ensemble(olib, inp1, threads=1)
+    log(f"cpu_baseline: {ncol} columns x {steps} step(s) on {used} threads: {dt:.3f} s/step")
+    n1 = 1 if lbl else 200
+    e1 = ensemble(_subset(inp_full, n1), 1)
     t0 = time.perf_counter()
-    e1.step(1)
-    dt1 = time.perf_counter() - t0
-    log(f"cpu_baseline: 1 column x 1 step on 1 thread in {dt1:.2f} s")
-    return {"value": ncol / dt, "unit": "column-timesteps/s", "cores": used, "kind": "port",
-            "sample": f"{ncol} columns x 1 step x {n_nodes - 1} bands, OpenMP over columns, gcc -O2",
-            "single_core_value": 1.0 / dt1}, e
+    e1.step(steps)
+    dt1 = (time.perf_counter() - t0) / steps / n1
+    log(f"cpu_baseline: one column-timestep on 1 thread: {dt1 * 1e3:.3f} ms")
+    # radiative transfer alone (main.cpp:320-344) on the optical depths of column 0, one core
+    tau = np.ascontiguousarray(e1.get_tau(0))
+    nspec = tau.shape[0]
+    st = e1.get_state()
+    dp = C.POINTER(C.c_double)
+    Ed, Eu, dE = np.zeros(21), np.zeros(21), np.zeros(20)
+    if lbl:
+        wvl, wgt, mode = np.ascontiguousarray(inp_full["wvl"]), np.ones(nspec), 1
+    else:
+        wvl, wgt, mode = (np.ascontiguousarray(inp_full["table"]["wvl"]),
+                          np.ascontiguousarray(inp_full["table"]["weight"]), 0)
+    Tl = np.ascontiguousarray(st["Tlayer"][0])
+    reps = 1 if lbl else 300
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        olib.orc_radiative_transfer(nspec, 20, 30, tau.ctypes.data_as(dp), wvl.ctypes.data_as(dp),
+                                    wgt.ctypes.data_as(dp), mode, Tl.ctypes.data_as(dp), float(st["T_surface"][0]),
+                                    float(inp_full["solar"]), Ed.ctypes.data_as(dp), Eu.ctypes.data_as(dp),
+                                    dE.ctypes.data_as(dp))
+    dt_rt = (time.perf_counter() - t0) / reps
+    log(f"cpu_baseline: radiative_transfer alone, one column on 1 thread: {dt_rt * 1e3:.3f} ms")
+    out = {"value": ncol / dt, "unit": "column-timesteps/s", "cores": used, "kind": "port",
+           "sample": f"{ncol} columns x {steps} step(s) x {nspec} spectral points, full step (adjustment, feedback, "
+                     "optical depths, RT, time step), OpenMP over columns, gcc -O2 -ffp-contract=off",
+           "single_core_value": 1.0 / dt1, "single_core_rt_only_value": 1.0 / dt_rt}
+    if not lbl:
+        # informational (BASELINE.md section 3 (i)): the reference re-opens and re-reads the table every step
+        # (repwvl_thermal.cpp:114, 205-208); here: one parse of the flattened table per column-step on top
+        path = os.path.join(ROOT, "tests", "golden", "Reduced100Forcing.rtab")
+        dims, blob = (C.c_longlong * 4)(), dp()
+        t0 = time.perf_counter()
+        for _ in range(20):
+            olib.orc_rtab_load(path.encode(), dims, C.byref(blob))
+            olib.orc_free(blob)
+        dt_load = (time.perf_counter() - t0) / 20
+        out["single_core_reread_table_per_step_value"] = 1.0 / (dt1 + dt_load)
+    return out
+
+
+def valu_issue(tag, kernel_substr, points_per_launch, rt_avg_s):
+    """fp64 VALU issue fraction: committed instruction count per spectral point x this run's HIP-event time.
+    Every wave64 VALU instruction holds its SIMD for 4 cycles.  None when the committed counters belong to
+    another build of the kernels."""
+    try:
+        pmc = json.load(open(os.path.join(ROOT, "profiles", f"{tag}_pmc.json")))
+        if pmc.get("kernel_source_id") != kernel_source_id() or kernel_substr not in pmc["kernel"]:
+            return None, pmc
+        ipp = pmc["derived"]["valu_instructions_per_point"]
+        return {"instructions_per_64_points": ipp * 64, "source": f"profiles/{tag}_pmc.json",
+                "kernel_source_id": pmc["kernel_source_id"],
+                "issue_frac_at_2.4GHz": ipp * points_per_launch * 4 / (N_SIMD * NOMINAL_CLOCK_HZ * rt_avg_s)}, pmc
+    except (OSError, KeyError, ValueError):
+        return None, None
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=4)
-    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=None)
+    ap.add_argument("--warmup", type=int, default=None)
+    ap.add_argument("--workload", choices=("lbl", "repwvl100"), default="lbl")
     ap.add_argument("--ncol", type=int, default=10000, help="columns in the whole ensemble")
     ap.add_argument("--nodes", type=int, default=131072, help="wavelength nodes of the lbl spectrum")
     ap.add_argument("--scaling", choices=("strong", "weak"), default="strong")
@@ -83,7 +168,14 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--backend", default="nccl", choices=("nccl", "gloo"),
                     help="torch.distributed backend; gloo only to rehearse the N>1 path on a one-GPU box")
+    ap.add_argument("--dump-state", default=None,
+                    help="rank 0 writes the gathered [ncol][21] state to this .npy file (multi-rank parity tests)")
     args = ap.parse_args()
+    lbl = args.workload == "lbl"
+    if args.steps is None:
+        args.steps = 4 if lbl else 400
+    if args.warmup is None:
+        args.warmup = 1 if lbl else 20
 
     # stdout carries exactly ONE line, the JSON: libraries that print banners to fd 1 (RCCL does when its
     # communicator comes up) are sent to stderr until the result is ready
@@ -121,25 +213,34 @@ def main():
 
     import our_first_climate_model_amd as pkg
     from our_first_climate_model_amd.distributed import gather_state, shard_bounds
-    import helpers as H
 
     ncol_total = args.ncol * (world if args.scaling == "weak" else 1)
     lo, hi = shard_bounds(ncol_total, rank, world)
     ncol_local = hi - lo
 
     t_setup = time.perf_counter()
-    atm_cols, _ = pkg.atm_load(os.path.join(ROOT, "tests", "golden", "fpda.lbl.atm"))
-    spec = pkg.perturbation_sweep(ncol_local, perturb_rh=True, perturb_ts=True, first=lo, total=ncol_total)
-    cols = pkg.build_columns(atm_cols, spec, "lbl")
-    wvl, tabs = pkg.synth_lbl_tables(args.nodes, plevel=cols["plevel"])
-    inp = dict(mode="lbl", ncol=ncol_local, cols=cols, solar=pkg.default_solar()["solar_irr"], wvl=wvl, tabs=tabs)
+    golden = os.path.join(ROOT, "tests", "golden")
+    if lbl:
+        atm_cols, _ = pkg.atm_load(os.path.join(golden, "fpda.lbl.atm"))
+        spec = pkg.perturbation_sweep(ncol_local, perturb_rh=True, perturb_ts=True, first=lo, total=ncol_total)
+        cols = pkg.build_columns(atm_cols, spec, "lbl")
+        wvl, tabs = pkg.synth_lbl_tables(args.nodes, plevel=cols["plevel"])
+        inp = dict(mode="lbl", ncol=ncol_local, cols=cols, solar=pkg.default_solar()["solar_irr"], wvl=wvl, tabs=tabs)
+        nspec = args.nodes - 1
+    else:
+        atm_cols, _ = pkg.atm_load(os.path.join(golden, "test.atm"))
+        spec = pkg.perturbation_sweep(ncol_local, first=lo, total=ncol_total)  # configs[2]: the CO2 ppm sweep
+        cols = pkg.build_columns(atm_cols, spec, "repwvl")
+        table = pkg.read_rtab(os.path.join(golden, "Reduced100Forcing.rtab"))
+        inp = dict(mode="repwvl", ncol=ncol_local, cols=cols, solar=pkg.default_solar()["solar_irr"], table=table)
+        nspec = table["n_wvl"]
     stream = torch.cuda.current_stream().cuda_stream
-    ens = H.configure(pkg.Ensemble(ncol_local, device=dev_index, stream=stream), inp)
+    ens = pkg.configure(pkg.Ensemble(ncol_local, device=dev_index, stream=stream), inp)
     if args.chunks:
         ens.set_spectral_chunks(args.chunks)
     packed = torch.empty((ncol_local, 21), dtype=torch.float64, device="cuda")
     log(f"setup {time.perf_counter() - t_setup:.1f} s: {ncol_total} columns ({ncol_local} on this rank), "
-        f"{args.nodes - 1} bands, {ens.get_spectral_chunks()} spectral chunks/column")
+        f"{nspec} spectral points, {ens.get_spectral_chunks()} partial records/column")
 
     def barrier():
         torch.cuda.synchronize()
@@ -174,48 +275,57 @@ def main():
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     elapsed = float(tmax.item())
     assert final.shape == (ncol_total, 21) and bool(torch.isfinite(final).all())
+    if args.dump_state and rank == 0:
+        np.save(args.dump_state, final.cpu().numpy())
 
     if rank == 0:
-        nband = args.nodes - 1
         rt_avg_s = rt_ms / 1e3 / max(rt_n, 1)
-        alg_bytes = BYTES_PER_BAND * nband * ncol_local  # per RT launch on this rank
+        per_point = BYTES_PER_BAND if lbl else BYTES_PER_RWVL
+        alg_bytes = per_point * nspec * ncol_local  # per RT launch on this rank
         achieved = alg_bytes / rt_avg_s / 1e9
-        # HBM bytes per launch from the PMC passes committed under profiles/ (FETCH_SIZE x 2 + WRITE_SIZE,
-        # MI355X_MICROARCH.md HBM section); only valid for the workload they were collected on
-        traffic, traffic_src, valu = None, None, None
+        tag = "r02_lbl" if lbl else "r02_repwvl100"
+        kern = "k_rt_lbl_pair" if lbl else "k_rt_repwvl_flat"
+        valu, pmc = valu_issue(tag, kern, nspec * ncol_local, rt_avg_s)
+        # HBM bytes per launch from the PMC passes committed under profiles/ (2 x FETCH_SIZE + WRITE_SIZE, the
+        # gfx950 correction of MI355X_MICROARCH.md's HBM section); only valid for the workload they were collected on
+        traffic, traffic_src = None, None
         try:
-            pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_final_pmc.json")))
-            prof = pmc["hbm_traffic"]
-            if prof["algorithmic_bytes_per_launch"] == alg_bytes:
-                traffic, traffic_src = prof["traffic_bytes_per_launch"], "profiles/r01_final_pmc.json"
-            # the bound that actually holds: every wave64 VALU instruction occupies its SIMD for 4 cycles;
-            # instruction count per 64 bands from the committed PMC pass, time from this run's HIP events
-            ipb = pmc["derived"]["valu_instructions_per_64_bands"]
-            valu = {"instructions_per_64_bands": ipb, "source": "profiles/r01_final_pmc.json",
-                    "issue_frac_at_2.4GHz": ipb * (nband * ncol_local / 64.0) * 4 / (1024 * 2.4e9 * rt_avg_s)}
-        except (OSError, KeyError, ValueError):
+            if pmc["hbm_traffic"]["algorithmic_bytes_per_launch"] == alg_bytes:
+                traffic, traffic_src = pmc["hbm_traffic"]["traffic_bytes_per_launch"], f"profiles/{tag}_pmc.json"
+        except (TypeError, KeyError):
             pass
+        if lbl:
+            workload = (f"{ncol_total}-column ensemble x full lbl.arts 5-species spectrum (BASELINE.json configs[3] "
+                        "at the default 10000); spectra synthetic, seeded")
+            config = {"workload": workload, "columns_total": ncol_total, "columns_per_gpu": ncol_local,
+                      "lbl_nodes": args.nodes, "bands": nspec, "layers": 20, "angles": 30,
+                      "atmosphere": "fpda.lbl.atm",
+                      "perturbations": "CO2 x linspace(0.5,4), RH x (1+0.1u), T_surface 288.2+2u"}
+            note = ("numerator = 808 B per (column, band), as if every column streamed the 5 species tables itself "
+                    "(SURVEY 8d); the tables are shared, real HBM traffic is ~1% of that and the kernel is "
+                    "fp64-VALU-issue bound (profiles/README.md)")
+        else:
+            workload = (f"{ncol_total}-column ensemble (CO2 ppm sweep) x repwvl Reduced100Forcing (BASELINE.json "
+                        "configs[2] at the default 10000); the reference's own table")
+            config = {"workload": workload, "columns_total": ncol_total, "columns_per_gpu": ncol_local,
+                      "wavelengths": nspec, "layers": 20, "angles": 30, "atmosphere": "test.atm",
+                      "perturbations": "CO2 x linspace(0.5,4)"}
+            note = ("numerator = 26 584 B per (column, wavelength): the xsec table slice + (lambda, weight), as if "
+                    "every column read the table itself (SURVEY 8d); the 2.66 MB table lives in L2, the kernel is "
+                    "fp64-VALU-issue bound (profiles/README.md)")
+        config["parallelism"] = f"columns sharded over {world} GPU(s), one all-gather at the end"
         out = {
             "metric": "column_timesteps_per_sec", "value": ncol_total * args.steps / elapsed,
             "unit": "column-timesteps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": args.scaling,
-            "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": f"{ncol_total}-column ensemble x full lbl.arts 5-species spectrum "
-                                   "(BASELINE.json configs[3] at the default 10000); spectra synthetic, seeded",
-                       "columns_total": ncol_total, "columns_per_gpu": ncol_local, "lbl_nodes": args.nodes,
-                       "bands": nband, "layers": 20, "angles": 30, "atmosphere": "fpda.lbl.atm",
-                       "perturbations": "CO2 x linspace(0.5,4), RH x (1+0.1u), T_surface 288.2+2u",
-                       "parallelism": f"columns sharded over {world} GPU(s), one all-gather at the end"},
-            "roofline": {"bound": "hbm", "kernel": "k_rt_lbl_pair", "achieved": achieved, "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
-                         "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": rt_avg_s * 1e3,
-                         "launches": rt_n, "fp64_valu_issue": valu,
-                         "note": "numerator = 808 B per (column, band), as if every column streamed the 5 species "
-                                 "tables itself (SURVEY 8d); the tables are shared, real HBM traffic is ~1% of "
-                                 "that and the kernel is fp64-VALU-issue bound (94% VALU busy, profiles/README.md)"},
+            "vs_baseline": None, "dtype": "f64", "data": "synthetic", "config": config,
+            "roofline": {"bound": "hbm", "actual_bound": "fp64_valu_issue", "kernel": kern, "achieved": achieved,
+                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "traffic_source": traffic_src, "algorithmic_bytes_per_launch": alg_bytes,
+                         "avg_launch_ms": rt_avg_s * 1e3, "launches": rt_n, "fp64_valu_issue": valu, "note": note},
         }
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"], oe = cpu_baseline(pkg, inp, args.nodes, log)
+            out["cpu_baseline"] = cpu_baseline(pkg, inp, args.workload, log)
         sys.stdout.flush()
         os.dup2(stdout_fd, 1)
         print(json.dumps(out), flush=True)

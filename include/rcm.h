@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define RCM_ABI_VERSION 1
+#define RCM_ABI_VERSION 2
 
 #define RCM_OK 0
 #define RCM_ERR_ARG (-1)    /* bad argument / unsupported size            */
@@ -144,14 +144,35 @@ int rcm_get_profile(rcm_ensemble *h, int col, double *Tlayer_adj, double *theta,
  * cloud_into_tau (or the lbl assembly) handed to the most recent radiative_transfer; before the first
  * step: what they will hand to it (the initial, not yet adjusted profile, main.cpp:500). */
 int rcm_get_tau(rcm_ensemble *h, int col, double *tau);
+/* The same optical depths AS THE PRODUCTION KERNELS FORM THEM (diagnostic; parity of rows a5 / a9): rcm_get_tau
+ * evaluates read_tau's corner-DIFFERENCE form (repwvl_thermal.cpp:235-241); the thermal-RT kernels interpolate
+ * with numDens-folded corner WEIGHTS and clamp to [-10, 1e7].  This getter runs the very device
+ * functions of those kernels (column image + per-point optical-depth stage) and returns what they feed to
+ * the sweep, same layout and same timing rules as rcm_get_tau. */
+int rcm_get_tau_production(rcm_ensemble *h, int col, double *tau);
 /* Current gas block [ncol][ngas][nlayer] (H2O row follows the feedback). */
 int rcm_get_gas(rcm_ensemble *h, double *gas);
 int rcm_nspectral(rcm_ensemble *h); /* n_wvl (repwvl) or n_nodes-1 (lbl); <0 if unset */
 
 /* Multi-GPU hand-off: writes [ncol][nlayer+1] = (Tlayer[0..nlayer-1], T_surface) to the DEVICE
  * buffer `dev_out` on the handle's stream.  The caller all-gathers it (RCCL; one collective,
- * SURVEY section 8e).  No host copy. */
+ * SURVEY section 8e).  No host copy.
+ * ORDERING: the pack kernel runs on the HANDLE's stream.  A handle created with stream = NULL owns a
+ * private stream (torch's default stream has the handle value 0 = NULL, so passing
+ * torch.cuda.current_stream().cuda_stream on the default stream also means "create your own"): call
+ * rcm_sync(h) -- or record an event on that stream -- before a collective on any OTHER stream reads
+ * `dev_out`, or the collective races the pack. */
 int rcm_pack_state(rcm_ensemble *h, void *dev_out);
+
+/* The one collective of the multi-GPU run, done by the library: packs this
+ * handle's [ncol][nlayer+1] block, zero-pads it to ncol_pad rows (every rank passes the same ncol_pad >=
+ * its own ncol, normally ceil(N_total/ranks)) and enqueues ONE ncclAllGather of ncol_pad*(nlayer+1)
+ * doubles per rank on the handle's stream.  `nccl_comm` is the caller's ncclComm_t (RCCL), passed as void*;
+ * `dev_recv` is a DEVICE buffer [ranks][ncol_pad][nlayer+1].  Asynchronous: rcm_sync(h) before reading it.
+ * The library calls the ncclAllGather of the RCCL already loaded in the process (the one the communicator
+ * was made with) and fails with RCM_ERR_STATE when there is none.  With several handles in ONE process
+ * (one per GPU), bracket the calls with ncclGroupStart/ncclGroupEnd as for any RCCL collective. */
+int rcm_gather(rcm_ensemble *h, void *nccl_comm, void *dev_recv, int ncol_pad);
 
 /* Launch geometry override for the thermal-RT kernel (0 = automatic): number of spectral
  * chunks each column is split into. */

@@ -34,24 +34,8 @@ def _f64(a, shape=None, name="array"):
     return a
 
 
-def lib():
-    """Loads the HIP library; fails loudly when it has not been built (no fallback)."""
-    global _lib
-    if _lib is not None:
-        return _lib
-    # One HIP runtime per process: PyTorch ships its own libamdhip64.so.7 / libhsa-runtime64; if this
-    # library were loaded first it would pull /opt/rocm's copy in and the second runtime to initialise
-    # finds no device (observed on the MI355X box).  Importing torch first makes the loader resolve our
-    # DT_NEEDED libamdhip64.so.7 to the copy torch already mapped.  Without torch (C++ driver) the
-    # system runtime is the only one and is used as is.
-    try:
-        import torch  # noqa: F401
-    except ImportError:
-        pass
-    if not os.path.exists(LIB_PATH):
-        raise ImportError(f"{LIB_PATH} is missing: build it with `python -m our_first_climate_model_amd.build` "
-                          "(hipcc --offload-arch=gfx950). There is no CPU fallback.")
-    L = C.CDLL(LIB_PATH)
+def _configure(L):
+    """Declares the argument types of every entry point of include/rcm.h on a loaded library."""
     vp = C.c_void_p
     L.rcm_abi_version.restype = C.c_int
     L.rcm_last_error.restype = C.c_char_p
@@ -76,6 +60,8 @@ def lib():
     L.rcm_get_fluxes.argtypes = [vp, _dp, _dp, _dp]
     L.rcm_get_profile.argtypes = [vp, C.c_int, _dp, _dp, _fp]
     L.rcm_get_tau.argtypes = [vp, C.c_int, _dp]
+    L.rcm_get_tau_production.argtypes = [vp, C.c_int, _dp]
+    L.rcm_gather.argtypes = [vp, vp, vp, C.c_int]
     L.rcm_get_gas.argtypes = [vp, _dp]
     L.rcm_nspectral.argtypes = [vp]
     L.rcm_pack_state.argtypes = [vp, vp]
@@ -94,13 +80,40 @@ def lib():
     L.rcm_free.restype = None
     L.rcm_write_banner.argtypes = [vp, C.c_double, C.c_double, _dp]
     L.rcm_write_profile.argtypes = [vp, C.c_int, _dp, _dp, _dp, C.c_float]
-    _lib = L
     return L
 
 
-def _ck(rc):
+
+
+def load_library(path):
+    """dlopens a build of the C-ABI library (RTLD_LOCAL) and declares its entry points.  The product is
+    LIB_PATH; tests load the variants build (tests/_variants, -DRCM_WITH_VARIANTS) beside it."""
+    # One HIP runtime per process: PyTorch ships its own libamdhip64.so.7 / libhsa-runtime64; if this
+    # library were loaded first it would pull /opt/rocm's copy in and the second runtime to initialise
+    # finds no device (observed on the MI355X box).  Importing torch first makes the loader resolve our
+    # DT_NEEDED libamdhip64.so.7 to the copy torch already mapped.  Without torch (C++ driver) the
+    # system runtime is the only one and is used as is.
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
+    if not os.path.exists(path):
+        raise ImportError(f"{path} is missing: build it with `python -m our_first_climate_model_amd.build` "
+                          "(hipcc --offload-arch=gfx950). There is no CPU fallback.")
+    return _configure(C.CDLL(path))
+
+
+def lib():
+    """Loads the HIP library; fails loudly when it has not been built (no fallback)."""
+    global _lib
+    if _lib is None:
+        _lib = load_library(LIB_PATH)
+    return _lib
+
+
+def _ck(rc, L=None):
     if rc != 0:
-        raise RcmError(rc, lib().rcm_last_error().decode(errors="replace"))
+        raise RcmError(rc, (L or lib()).rcm_last_error().decode(errors="replace"))
 
 
 # ------------------------------------------------------------------------------------------------
@@ -204,16 +217,21 @@ def read_rtab(path):
 class Ensemble:
     """An ensemble of independent columns on one MI355X (rcm_ensemble, include/rcm.h)."""
 
-    def __init__(self, ncol, nlayer=20, nangle=30, device=0, stream=None):
+    def __init__(self, ncol, nlayer=20, nangle=30, device=0, stream=None, library=None):
+        """`library`: a build from load_library() other than the product (tests: the variants build)."""
         self.ncol, self.nlayer, self.nangle, self.device = ncol, nlayer, nangle, device
         self.ngas = None
+        self._L = library if library is not None else lib()
         self.h = C.c_void_p()
-        _ck(lib().rcm_create(ncol, nlayer, nangle, device, C.c_void_p(stream) if stream else None,
-                             C.byref(self.h)))
+        self._ck(self._L.rcm_create(ncol, nlayer, nangle, device, C.c_void_p(stream) if stream else None,
+                                    C.byref(self.h)))
+
+    def _ck(self, rc):
+        _ck(rc, self._L)
 
     def close(self):
         if getattr(self, "h", None):
-            lib().rcm_destroy(self.h)
+            self._L.rcm_destroy(self.h)
             self.h = C.c_void_p()
 
     def __del__(self):
@@ -229,10 +247,10 @@ class Ensemble:
         self.close()
 
     def set_grid(self, plevel):
-        _ck(lib().rcm_set_grid(self.h, _p(_f64(plevel, (self.nlayer + 1,), "plevel"))))
+        self._ck(self._L.rcm_set_grid(self.h, _p(_f64(plevel, (self.nlayer + 1,), "plevel"))))
 
     def set_forcing(self, solar_irr, cloud_layer=17, cloud_tau=1.0):
-        _ck(lib().rcm_set_forcing(self.h, solar_irr, cloud_layer, cloud_tau))
+        self._ck(self._L.rcm_set_forcing(self.h, solar_irr, cloud_layer, cloud_tau))
 
     def set_column_forcing(self, solar_irr=None, cloud_layer=None, cloud_tau=None):
         a = None if solar_irr is None else _f64(solar_irr, (self.ncol,), "solar_irr")
@@ -240,35 +258,35 @@ class Ensemble:
         c = None if cloud_tau is None else _f64(cloud_tau, (self.ncol,), "cloud_tau")
         if b is not None and b.shape != (self.ncol,):
             raise ValueError("cloud_layer: expected shape (ncol,)")
-        _ck(lib().rcm_set_column_forcing(self.h, _p(a), None if b is None else b.ctypes.data_as(_ip), _p(c)))
+        self._ck(self._L.rcm_set_column_forcing(self.h, _p(a), None if b is None else b.ctypes.data_as(_ip), _p(c)))
 
     def solar_setup_columns(self, tau_s, mu_s, albedo, doublings=20, g_asym=0.85, daytime=0.5, E_0=1361.0):
         """main.cpp:214-264 on the device per column; returns [ncol][7] (r_dir, s_dir, t_dir, r, t, r_total,
         solar_irr) and installs solar_irr and cloud_tau = tau_s/2 (main.cpp:267) per column."""
         out = np.zeros((self.ncol, 7))
-        _ck(lib().rcm_solar_setup_columns(self.h, _p(_f64(tau_s, (self.ncol,))), _p(_f64(mu_s, (self.ncol,))),
+        self._ck(self._L.rcm_solar_setup_columns(self.h, _p(_f64(tau_s, (self.ncol,))), _p(_f64(mu_s, (self.ncol,))),
                                           _p(_f64(albedo, (self.ncol,))), doublings, g_asym, daytime, E_0, _p(out)))
         return out
 
     def get_residual(self):
         r = np.zeros(self.ncol)
-        _ck(lib().rcm_get_residual(self.h, _p(r)))
+        self._ck(self._L.rcm_get_residual(self.h, _p(r)))
         return r
 
     def run_to_equilibrium(self, tol_K, max_steps, check_every=10):
         done, worst = C.c_int(0), C.c_double(0)
-        _ck(lib().rcm_run_to_equilibrium(self.h, tol_K, max_steps, check_every, C.byref(done), C.byref(worst)))
+        self._ck(self._L.rcm_run_to_equilibrium(self.h, tol_K, max_steps, check_every, C.byref(done), C.byref(worst)))
         return done.value, worst.value
 
     def checkpoint_save(self, path):
-        _ck(lib().rcm_checkpoint_save(self.h, os.fsencode(path)))
+        self._ck(self._L.rcm_checkpoint_save(self.h, os.fsencode(path)))
 
     def checkpoint_load(self, path):
-        _ck(lib().rcm_checkpoint_load(self.h, os.fsencode(path)))
+        self._ck(self._L.rcm_checkpoint_load(self.h, os.fsencode(path)))
 
     def set_repwvl_tables(self, t):
         arrs = [_f64(t[k]) for k in ("p_grid", "t_ref", "t_pert", "wvl", "weight", "xsec")]
-        _ck(lib().rcm_set_repwvl_tables(self.h, t["n_tpert"], t["n_species"], t["n_wvl"], t["n_p"],
+        self._ck(self._L.rcm_set_repwvl_tables(self.h, t["n_tpert"], t["n_species"], t["n_wvl"], t["n_p"],
                                         *[_p(a) for a in arrs]))
         self.ngas = NSPEC_REPWVL
 
@@ -279,7 +297,7 @@ class Ensemble:
             raise ValueError("need 5 species tables (CO2, H2O, O3, CH4, N2O)")
         h2o_ref = _f64(h2o_ref, (self.nlayer,), "h2o_ref")
         arr = (_dp * NSPEC_LBL)(*[_p(x) for x in tabs])
-        _ck(lib().rcm_set_lbl_tables(self.h, wvl.size, _p(wvl), arr, _p(h2o_ref)))
+        self._ck(self._L.rcm_set_lbl_tables(self.h, wvl.size, _p(wvl), arr, _p(h2o_ref)))
         self.ngas = NSPEC_LBL
 
     def set_columns(self, Tlayer0, T_surface0, gas, rel_hum):
@@ -289,69 +307,96 @@ class Ensemble:
         Ts = _f64(T_surface0, (self.ncol,), "T_surface0")
         g = _f64(gas, (self.ncol, self.ngas, self.nlayer), "gas")
         rh = _f64(rel_hum, (self.ncol, self.nlayer), "rel_hum")
-        _ck(lib().rcm_set_columns(self.h, _p(T), _p(Ts), _p(g), _p(rh)))
+        self._ck(self._L.rcm_set_columns(self.h, _p(T), _p(Ts), _p(g), _p(rh)))
 
     def step(self, n=1):
-        _ck(lib().rcm_step(self.h, n))
+        self._ck(self._L.rcm_step(self.h, n))
 
     def sync(self):
-        _ck(lib().rcm_sync(self.h))
+        self._ck(self._L.rcm_sync(self.h))
 
     def get_state(self):
         T = np.zeros((self.ncol, self.nlayer))
         Ts = np.zeros(self.ncol)
         tm = np.zeros(self.ncol, dtype=np.float32)
         dt = np.zeros(self.ncol)
-        _ck(lib().rcm_get_state(self.h, _p(T), _p(Ts), tm.ctypes.data_as(_fp), _p(dt)))
+        self._ck(self._L.rcm_get_state(self.h, _p(T), _p(Ts), tm.ctypes.data_as(_fp), _p(dt)))
         return dict(Tlayer=T, T_surface=Ts, time_h=tm, timestep=dt)
 
     def get_fluxes(self):
         Ed = np.zeros((self.ncol, self.nlayer + 1))
         Eu = np.zeros((self.ncol, self.nlayer + 1))
         dE = np.zeros((self.ncol, self.nlayer))
-        _ck(lib().rcm_get_fluxes(self.h, _p(Ed), _p(Eu), _p(dE)))
+        self._ck(self._L.rcm_get_fluxes(self.h, _p(Ed), _p(Eu), _p(dE)))
         return dict(E_down=Ed, E_up=Eu, dE=dE)
 
     def get_profile(self, col=0):
         T = np.zeros(self.nlayer)
         th = np.zeros(self.nlayer)
         tm = C.c_float(0)
-        _ck(lib().rcm_get_profile(self.h, col, _p(T), _p(th), C.byref(tm)))
+        self._ck(self._L.rcm_get_profile(self.h, col, _p(T), _p(th), C.byref(tm)))
         return T, th, tm.value
 
     def nspectral(self):
-        n = lib().rcm_nspectral(self.h)
+        n = self._L.rcm_nspectral(self.h)
         if n < 0:
-            _ck(n)
+            self._ck(n)
         return n
 
     def get_tau(self, col=0):
         tau = np.zeros((self.nspectral(), self.nlayer))
-        _ck(lib().rcm_get_tau(self.h, col, _p(tau)))
+        self._ck(self._L.rcm_get_tau(self.h, col, _p(tau)))
+        return tau
+
+    def get_tau_production(self, col=0):
+        """The optical depths as the production kernels form them (rcm_get_tau_production)."""
+        tau = np.zeros((self.nspectral(), self.nlayer))
+        self._ck(self._L.rcm_get_tau_production(self.h, col, _p(tau)))
         return tau
 
     def get_gas(self):
         g = np.zeros((self.ncol, self.ngas, self.nlayer))
-        _ck(lib().rcm_get_gas(self.h, _p(g)))
+        self._ck(self._L.rcm_get_gas(self.h, _p(g)))
         return g
 
     def pack_state(self, dev_ptr):
         """Writes [ncol][nlayer+1] (Tlayer, T_surface) to a DEVICE pointer (e.g. tensor.data_ptr())."""
-        _ck(lib().rcm_pack_state(self.h, C.c_void_p(dev_ptr)))
+        self._ck(self._L.rcm_pack_state(self.h, C.c_void_p(dev_ptr)))
+
+    def gather(self, nccl_comm, dev_recv_ptr, ncol_pad):
+        """rcm_gather: pack + ONE ncclAllGather on the handle's stream; `nccl_comm` = the caller's ncclComm_t as
+        an integer, `dev_recv_ptr` = DEVICE pointer to [ranks][ncol_pad][nlayer+1] doubles.  Asynchronous."""
+        self._ck(self._L.rcm_gather(self.h, C.c_void_p(nccl_comm), C.c_void_p(dev_recv_ptr), ncol_pad))
 
     def set_spectral_chunks(self, n):
-        _ck(lib().rcm_set_spectral_chunks(self.h, n))
+        self._ck(self._L.rcm_set_spectral_chunks(self.h, n))
 
     def get_spectral_chunks(self):
-        n = lib().rcm_get_spectral_chunks(self.h)
+        n = self._L.rcm_get_spectral_chunks(self.h)
         if n < 0:
-            _ck(n)
+            self._ck(n)
         return n
 
     def set_rt_timing(self, on=True):
-        _ck(lib().rcm_set_rt_timing(self.h, 1 if on else 0))
+        self._ck(self._L.rcm_set_rt_timing(self.h, 1 if on else 0))
 
     def get_rt_timing(self):
         ms, n = C.c_double(0), C.c_int(0)
-        _ck(lib().rcm_get_rt_timing(self.h, C.byref(ms), C.byref(n)))
+        self._ck(self._L.rcm_get_rt_timing(self.h, C.byref(ms), C.byref(n)))
         return ms.value, n.value
+
+
+def configure(e, inp):
+    """Applies one input description to an ensemble handle in the order the ABI requires (grid, forcing,
+    spectral tables, columns).  `inp`: mode 'repwvl' (key 'table' = read_rtab dict) or 'lbl' (keys 'wvl',
+    'tabs'), 'cols' = build_columns(...), 'solar', optional 'cloud_layer' / 'cloud_tau'.  `e` is an Ensemble
+    or anything with the same four setters."""
+    c = inp["cols"]
+    e.set_grid(c["plevel"])
+    e.set_forcing(inp["solar"], inp.get("cloud_layer", 17), inp.get("cloud_tau", 1.0))
+    if inp["mode"] == "repwvl":
+        e.set_repwvl_tables(inp["table"])
+    else:
+        e.set_lbl_tables(inp["wvl"], inp["tabs"], c["h2o_ref"])
+    e.set_columns(c["Tlayer0"], c["T_surface0"], c["gas"], c["rel_hum"])
+    return e

@@ -22,11 +22,31 @@ def _newer(target, deps):
     return any(os.path.getmtime(d) > t for d in deps)
 
 
-def build(force=False, verbose=False):
+VARIANTS_LIB = os.path.join(ROOT, "tests", "_variants", "librcm_hip_variants.so")
+
+
+def _sources():
     srcs = [os.path.join(CSRC, s) for s in SOURCES]
     deps = srcs + [os.path.join(CSRC, h) for h in HEADERS] + [os.path.join(ROOT, "include", "rcm.h")]
     common = ["-O3", "-std=c++17", "-fPIC", "--offload-arch=gfx950", "-I" + os.path.join(ROOT, "include"),
               "-I" + CSRC, "-Wall", "-Wno-unused-function"]
+    return srcs, deps, common
+
+
+def build_variants(force=False):
+    """TEST-SIDE build of the same sources with -DRCM_WITH_VARIANTS: adds the one-lane-per-point reference
+    kernels (library exp, branch-for-branch cplkavg, no cube chains) and their selection by environment
+    variable.  Lives under tests/_variants/ and is loaded only by the tests that cross-check the production
+    kernels against them; the production library contains neither."""
+    srcs, deps, common = _sources()
+    if force or _newer(VARIANTS_LIB, deps):
+        os.makedirs(os.path.dirname(VARIANTS_LIB), exist_ok=True)
+        subprocess.run([HIPCC] + common + ["-DRCM_WITH_VARIANTS", "-shared", "-o", VARIANTS_LIB] + srcs, check=True)
+    return VARIANTS_LIB
+
+
+def build(force=False, verbose=False):
+    srcs, deps, common = _sources()
     if force or _newer(LIB, deps):
         cmd = [HIPCC] + common + ["-shared", "-o", LIB] + srcs
         if verbose:

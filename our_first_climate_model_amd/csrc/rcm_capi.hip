@@ -1,6 +1,7 @@
 // rcm_capi.hip -- the ensemble handle and the C ABI (include/rcm.h) on top of the gfx950 kernels of
 // rcm_kernels.hpp: device buffers, table upload and re-layout, launch geometry, step loop, getters,
 // restart files.  Host-only pieces of the reference driver live in rcm_host.cpp.
+#include <dlfcn.h>
 #include <hip/hip_runtime.h>
 
 #include <cmath>
@@ -47,6 +48,8 @@ struct rcm_ensemble {
   double *scratch = nullptr;  // 2*NL doubles
   double *partial_buf = nullptr;
   double *slice_buf = nullptr;  // [ncol][kPostSlices][42]: first stage of the chunk sum for few columns x many chunks
+  double *gather_send = nullptr;  // rcm_gather: this rank's zero-padded block [gather_rows][21]
+  int gather_rows = 0;
   // repwvl host copies needed to (re)derive per-layer constants
   std::vector<double> p_grid;
   int *d_ip = nullptr;
@@ -178,18 +181,12 @@ int ensure_partials(rcm_ensemble *h) {
   return RCM_OK;
 }
 
-template <int EXPV, int CUBE>
-void launch_rt(rcm_ensemble *h, int blocks) {
-  if (h->mode == rcm::MODE_LBL && EXPV == 1 && h->planck_fast && h->pair) {
+// The production kernels: lane pairs, cube/root-pair angle chains (CUBE = 1), own exp and narrow-band Planck.
+template <int CUBE>
+void launch_rt_pair(rcm_ensemble *h, int blocks) {
+  if (h->mode == rcm::MODE_LBL) {
     hipLaunchKernelGGL((rcm::k_rt_lbl_pair<CUBE>), dim3(blocks), dim3(64 * rcm::WPB), 0, h->stream, h->d);
-  } else if (h->mode == rcm::MODE_LBL) {
-#ifndef RCM_EXPERIMENT
-    if (!h->planck_fast)
-      hipLaunchKernelGGL((rcm::k_rt_lbl<EXPV, CUBE, 0>), dim3(blocks), dim3(64 * rcm::WPB), 0, h->stream, h->d);
-    else
-#endif
-      hipLaunchKernelGGL((rcm::k_rt_lbl<EXPV, CUBE, 1>), dim3(blocks), dim3(64 * rcm::WPB), 0, h->stream, h->d);
-  } else if (EXPV == 1 && use_flat(h)) {
+  } else if (use_flat(h)) {
     const int maxc = 31 / h->d.n_wvl + 2;
     const size_t lds = (size_t)rcm::WPB * ((size_t)maxc * sizeof(rcm::RepwvlPairLds) + (size_t)(rcm::NH + 1) * 64 * sizeof(double));
     const long waves = ((long)h->ncol * h->d.n_wvl + 31) / 32;
@@ -198,11 +195,48 @@ void launch_rt(rcm_ensemble *h, int blocks) {
       (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipLaunchKernelGGL(kern, dim3((unsigned)((waves + rcm::WPB - 1) / rcm::WPB)), dim3(64 * rcm::WPB), lds, h->stream,
                        h->d, maxc);
-  } else if (EXPV == 1 && h->pair) {
+  } else {
     hipLaunchKernelGGL((rcm::k_rt_repwvl_pair<CUBE>), dim3(blocks), dim3(64 * rcm::WPB), 0, h->stream, h->d);
+  }
+}
+
+#ifdef RCM_WITH_VARIANTS
+// Test-side library only (tests/_variants/librcm_hip_variants.so, -DRCM_WITH_VARIANTS): the one-lane-per-point
+// kernels with the library exp / the branch-for-branch cplkavg / no cube chains, selected by environment
+// variables at rcm_create.  The production library has neither these kernels nor the variables.
+template <int EXPV, int CUBE>
+void launch_rt_variant(rcm_ensemble *h, int blocks) {
+  if (h->mode == rcm::MODE_LBL) {
+    if (!h->planck_fast)
+      hipLaunchKernelGGL((rcm::k_rt_lbl<EXPV, CUBE, 0>), dim3(blocks), dim3(64 * rcm::WPB), 0, h->stream, h->d);
+    else
+      hipLaunchKernelGGL((rcm::k_rt_lbl<EXPV, CUBE, 1>), dim3(blocks), dim3(64 * rcm::WPB), 0, h->stream, h->d);
   } else {
     hipLaunchKernelGGL((rcm::k_rt_repwvl<EXPV, CUBE>), dim3(blocks), dim3(64 * rcm::WPB), 0, h->stream, h->d);
   }
+}
+#endif
+
+void launch_rt(rcm_ensemble *h, int blocks) {
+#ifdef RCM_WITH_VARIANTS
+  const bool production = h->exp_variant == 1 && h->pair && (h->mode != rcm::MODE_LBL || h->planck_fast);
+  if (!production) {
+    if (h->exp_variant == 0 && !h->cube)
+      launch_rt_variant<0, 0>(h, blocks);
+    else if (h->exp_variant == 0)
+      launch_rt_variant<0, 1>(h, blocks);
+    else if (!h->cube)
+      launch_rt_variant<1, 0>(h, blocks);
+    else
+      launch_rt_variant<1, 1>(h, blocks);
+    return;
+  }
+  if (!h->cube) {
+    launch_rt_pair<0>(h, blocks);
+    return;
+  }
+#endif
+  launch_rt_pair<1>(h, blocks);
 }
 
 int launch_step(rcm_ensemble *h) {
@@ -223,21 +257,7 @@ int launch_step(rcm_ensemble *h) {
     ++h->events_used;
     HIPCK(hipEventRecord(e0, h->stream));
   }
-#ifdef RCM_EXPERIMENT  // quick A/B builds: only the EXPV = 1 instantiations
-  if (!h->cube)
-    launch_rt<1, 0>(h, blocks);
-  else
-    launch_rt<1, 1>(h, blocks);
-#else
-  if (h->exp_variant == 0 && !h->cube)
-    launch_rt<0, 0>(h, blocks);
-  else if (h->exp_variant == 0 && h->cube)
-    launch_rt<0, 1>(h, blocks);
-  else if (h->exp_variant == 1 && !h->cube)
-    launch_rt<1, 0>(h, blocks);
-  else
-    launch_rt<1, 1>(h, blocks);
-#endif
+  launch_rt(h, blocks);
   if (h->timing) HIPCK(hipEventRecord(e1, h->stream));
   Dev dp = d;  // what k_post sums: the chunk records, or their slice sums
   if (h->slice_buf) {
@@ -294,11 +314,13 @@ int rcm_create(int ncol, int nlayer, int nangle, int device, void *stream, rcm_e
   rcm_ensemble *h = new (std::nothrow) rcm_ensemble();
   if (!h) return fail(RCM_ERR_NOMEM, "rcm_create: out of memory");
   h->ncol = ncol, h->nlayer = nlayer, h->nangle = nangle, h->device = device;
+#ifdef RCM_WITH_VARIANTS  // kernel selection by environment: test-side library only
   if (const char *v = std::getenv("RCM_EXP_VARIANT")) h->exp_variant = std::atoi(v) ? 1 : 0;
   if (const char *v = std::getenv("RCM_CUBE")) h->cube = std::atoi(v) ? 1 : 0;
   if (const char *v = std::getenv("RCM_PLANCK_FAST")) h->planck_fast = std::atoi(v) ? 1 : 0;
   if (const char *v = std::getenv("RCM_PAIR")) h->pair = std::atoi(v) ? 1 : 0;
   if (const char *v = std::getenv("RCM_FLAT")) h->flat = std::atoi(v) ? 1 : 0;
+#endif
   auto bail = [&](int rc) {
     rcm_destroy(h);
     return rc;
@@ -396,6 +418,7 @@ int rcm_destroy(rcm_ensemble *h) {
   for (void *p : h->allocs) (void)hipFree(p);
   if (h->partial_buf) (void)hipFree(h->partial_buf);
   if (h->slice_buf) (void)hipFree(h->slice_buf);
+  if (h->gather_send) (void)hipFree(h->gather_send);
   for (auto &ev : h->events) {
     (void)hipEventDestroy(ev.first);
     (void)hipEventDestroy(ev.second);
@@ -738,6 +761,23 @@ int rcm_get_tau(rcm_ensemble *h, int col, double *tau) {
   return RCM_OK;
 }
 
+int rcm_get_tau_production(rcm_ensemble *h, int col, double *tau) {
+  if (!h || !tau || col < 0 || col >= h->ncol) return fail(RCM_ERR_ARG, "rcm_get_tau_production: bad argument");
+  if (h->mode == rcm::MODE_NONE || !h->have_grid || !h->have_columns)
+    return fail(RCM_ERR_STATE, "rcm_get_tau_production: grid, tables and columns must be set first");
+  if (int rc = use_device(h)) return rc;
+  const size_t n = (size_t)h->d.nspec * NL;
+  double *buf = nullptr;
+  HIPCK(hipMalloc((void **)&buf, n * sizeof(double)));
+  hipLaunchKernelGGL(rcm::k_tau_pair, dim3((h->d.nspec + 31) / 32), dim3(64), 0, h->stream, h->d, col, buf);
+  hipError_t e = hipGetLastError();
+  if (e == hipSuccess) e = hipMemcpyAsync(tau, buf, n * sizeof(double), hipMemcpyDeviceToHost, h->stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+  (void)hipFree(buf);
+  if (e != hipSuccess) return fail(RCM_ERR_HIP, std::string("rcm_get_tau_production: ") + hipGetErrorString(e));
+  return RCM_OK;
+}
+
 int rcm_get_gas(rcm_ensemble *h, double *gas) {
   if (!h || !gas) return fail(RCM_ERR_ARG, "rcm_get_gas: bad argument");
   if (!h->have_columns) return fail(RCM_ERR_STATE, "rcm_get_gas: columns not set");
@@ -754,6 +794,57 @@ int rcm_pack_state(rcm_ensemble *h, void *dev_out) {
   const size_t n = (size_t)h->ncol * NLEV;
   hipLaunchKernelGGL(rcm::k_pack, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, h->stream, h->d, (double *)dev_out);
   HIPCK(hipGetLastError());
+  return RCM_OK;
+}
+
+// ncclAllGather of the caller's RCCL.  The communicator comes from the caller, so the call must go to the
+// very librccl the caller created it with: the symbol is looked up in the running process (global scope
+// first, then the already loaded librccl by name) instead of linking a second copy in -- PyTorch ships its
+// own librccl.so next to /opt/rocm's, and a communicator of one is garbage to the other.
+namespace {
+using allgather_fn = int (*)(const void *, void *, size_t, int, void *, hipStream_t);
+allgather_fn find_allgather(std::string *where) {
+  if (void *f = dlsym(RTLD_DEFAULT, "ncclAllGather")) {
+    *where = "global scope";
+    return (allgather_fn)f;
+  }
+  for (const char *name : {"librccl.so.1", "librccl.so"}) {
+    if (void *lib = dlopen(name, RTLD_NOW | RTLD_NOLOAD))
+      if (void *f = dlsym(lib, "ncclAllGather")) {
+        *where = name;
+        return (allgather_fn)f;
+      }
+  }
+  return nullptr;
+}
+}  // namespace
+
+int rcm_gather(rcm_ensemble *h, void *nccl_comm, void *dev_recv, int ncol_pad) {
+  if (!h || !nccl_comm || !dev_recv || ncol_pad < h->ncol)
+    return fail(RCM_ERR_ARG, "rcm_gather: bad argument (ncol_pad must be >= this handle's ncol)");
+  if (!h->have_columns) return fail(RCM_ERR_STATE, "rcm_gather: columns not set");
+  if (int rc = use_device(h)) return rc;
+  std::string where;
+  const allgather_fn allgather = find_allgather(&where);
+  if (!allgather)
+    return fail(RCM_ERR_STATE, "rcm_gather: no RCCL in this process (ncclAllGather not found): the communicator is the "
+                               "caller's, so the caller's librccl must be loaded before this call");
+  if (h->gather_rows < ncol_pad) {
+    if (h->gather_send) {
+      HIPCK(hipStreamSynchronize(h->stream));
+      HIPCK(hipFree(h->gather_send));
+      h->gather_send = nullptr;
+    }
+    HIPCK(hipMalloc((void **)&h->gather_send, (size_t)ncol_pad * NLEV * sizeof(double)));
+    h->gather_rows = ncol_pad;
+  }
+  const size_t blk = (size_t)ncol_pad * NLEV;
+  if (ncol_pad > h->ncol)  // the padding rows of the last shard travel as zeros
+    HIPCK(hipMemsetAsync(h->gather_send + (size_t)h->ncol * NLEV, 0, (size_t)(ncol_pad - h->ncol) * NLEV * sizeof(double),
+                         h->stream));
+  if (int rc = rcm_pack_state(h, h->gather_send)) return rc;
+  const int nrc = allgather(h->gather_send, dev_recv, blk, /* ncclFloat64 */ 8, nccl_comm, h->stream);
+  if (nrc != 0) return fail(RCM_ERR_HIP, "rcm_gather: ncclAllGather (" + where + ") returned " + std::to_string(nrc));
   return RCM_OK;
 }
 

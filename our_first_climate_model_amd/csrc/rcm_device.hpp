@@ -19,17 +19,26 @@ namespace rcm {
 // Transmission t = exp(-tau * s) with the per-angle constant a1 = -s*log2(e).
 // tau must already be clamped to [kTauMin, kTauMax] (once per band-layer, clamp_tau) so that
 // |k| < 2^31; v_ldexp_f64 takes care of k < -1022 (denormal, then 0).
-constexpr double kTauMin = -10.0;  // exp(+10*60) is still finite
+constexpr double kTauMin = -10.0;  // keeps |k| < 2^31; exp(+10/mu) overflows to +inf above 1/mu = 71 (nangle >= 36), as exp() would
 constexpr double kTauMax = 1.0e7;  // exp(-1e7) == 0 for every angle
 
-__device__ __forceinline__ double clamp_tau(double tau) { return fmin(fmax(tau, kTauMin), kTauMax); }
+// Clamp that keeps a NaN a NaN: v_max_f64 / v_min_f64 return the non-NaN operand, which would turn a NaN optical
+// depth (NaN in a mixing ratio, a relative humidity or a table) into tau = -10 and finite garbage downstream,
+// where the reference (and the oracle) propagate the NaN.  One compare and one select of the high word put it
+// back (the low word of a NaN does not matter while the high word keeps the quiet bit every arithmetic NaN has).
+__device__ __forceinline__ double clamp_tau(double tau) {
+  const double c = fmin(fmax(tau, kTauMin), kTauMax);
+  const int hi = (tau != tau) ? __double2hiint(tau) : __double2hiint(c);
+  return __hiloint2double(hi, __double2loint(c));
+}
 
 #ifndef RCM_EXP_DEG
-#define RCM_EXP_DEG 9  // degree of the 2^f polynomial of the transmissions (c0 = 1 exactly): max rel err
-                       // 10 -> 5.8e-16, 9 -> 3.7e-14 (default), 8 -> 2.1e-12.  Flux error of the kernel against a
-                       // long-double evaluation of the reference's sweep (tools/accuracy_vs_longdouble.py, 19 999
-                       // bands): 1.6e-13, 4.3e-13, 2.0e-11 W/m^2; the CPU reference itself: 2e-11.  Degree 8 is
-                       // 2.6 % faster; the contract is 1e-6 W/m^2.
+#define RCM_EXP_DEG 7  // polynomial of the transmissions' 2^f (c0 = 1 exactly), max rel err of t:
+                       //   7 (default): degree 7 for 2^(f/2), then one squaring -> 7.4e-13   (12 VALU instructions)
+                       //   8 -> 2.1e-12, 9 -> 3.7e-14, 10 -> 5.8e-16 on the full range     (12 / 13 / 14)
+                       // Flux error of the kernel against a long-double evaluation of the reference's sweep
+                       // (tools/accuracy_vs_longdouble.py, 19 999 bands): degree 10 1.6e-13, 9 4.3e-13, 7-half
+                       // 7e-13, 8 2.0e-11 W/m^2; the CPU reference itself: 2e-11.  The contract is 1e-6 W/m^2.
 #endif
 __device__ __forceinline__ double exp_trans(double tau, double a1) {
   constexpr double kMagic = 0x1.8p+52;
@@ -38,7 +47,12 @@ __device__ __forceinline__ double exp_trans(double tau, double a1) {
   // f = y - k with y = tau*a1 = -tau*s*log2(e): one FMA, exact up to the rounding of a1
   // (relative 1.1e-16 of y: <= 4e-15 of the result wherever t >= 1e-15)
   const double f = fma(tau, a1, -kf);
-#if RCM_EXP_DEG == 8
+#if RCM_EXP_DEG == 7
+  double q = kExp2Half7[7];  // 2^(f/2): the halving is folded into the coefficients
+#pragma unroll
+  for (int i = 6; i >= 0; --i) q = fma(q, f, kExp2Half7[i]);
+  q *= q;
+#elif RCM_EXP_DEG == 8
   double q = kExp2Poly8[8];
 #pragma unroll
   for (int i = 7; i >= 0; --i) q = fma(q, f, kExp2Poly8[i]);
@@ -107,7 +121,6 @@ __device__ inline double cplkavg_dev(double wnumlo, double wnumhi, double t, dou
     }
     return tpre * kConc * val;                                    // :181
   }
-  const double vcp[7] = {10.25, 5.7, 3.9, 2.9, 2.3, 1.9, 0.0};
   double d[2] = {0., 0.}, p[2] = {0., 0.};
   int smallv = 0;
   const double v[2] = {v0, v1};
@@ -119,8 +132,10 @@ __device__ inline double cplkavg_dev(double wnumlo, double wnumhi, double t, dou
       const double vsq = vi * vi;
       p[i] = kConc * vsq * vi * (A1 + vi * (A2 + vi * (A3 + vsq * (A4 + vsq * (A5 + vsq * A6)))));
     } else {
-      int mmax = 1;
-      while (vi < vcp[mmax - 1]) mmax++;                          // :203
+      // :203  `while (vi < vcp[mmax-1]) mmax++` over vcp = {10.25, 5.7, 3.9, 2.9, 2.3, 1.9, 0.0}: the table
+      // decreases, so the loop stops at the first entry not above vi = the number of entries above vi
+      // (vi >= VCUT here, the closing 0.0 never counts).  Compares instead of an indexed table: no scratch.
+      const int mmax = 1 + (vi < 10.25) + (vi < 5.7) + (vi < 3.9) + (vi < 2.9) + (vi < 2.3) + (vi < 1.9);
       const double ex = exp(-vi);
       double exm = 1., di = 0.;
       for (int m = 1; m <= mmax; m++) {

@@ -76,6 +76,7 @@ struct Dev {
   unsigned species_mask;
 };
 
+#ifdef RCM_WITH_VARIANTS  // one-lane-per-point reference variants: test-side library only (tests/_variants)
 // ---------------------------------------------------------------------------------------------
 // Schwarzschild sweep for one angle (main.cpp:297-315) on the lane's spectral point.
 // t[l] = exp(-tau_l/mu).  The reference's L = (1-alpha)*L + alpha*B with alpha = 1-t is
@@ -163,6 +164,8 @@ __device__ __forceinline__ void store_partial(const Dev &d, int col, int chunk, 
   }
 }
 
+#endif  // RCM_WITH_VARIANTS
+
 // ---------------------------------------------------------------------------------------------
 // lbl optical depth of band b (DESIGN.md "lbl composition"; format lbl.arts/README:5-17):
 // tau_l = sum_s scale[s][l] * tab_s[b][l] (+ grey cloud, main.cpp:266-274).
@@ -230,6 +233,7 @@ __device__ __forceinline__ double repwvl_tau_layer(const Dev &d, const RepwvlLds
   return acc;
 }
 
+#ifdef RCM_WITH_VARIANTS
 // ---------------------------------------------------------------------------------------------
 // Thermal RT, lbl spectra: radiative_transfer (main.cpp:320-344) with the band Planck source
 // cplkavg (cplkavg.cpp:124-243) and optical depths assembled on the fly.
@@ -298,6 +302,8 @@ __global__ __launch_bounds__(64 * WPB, RCM_LB) void k_rt_lbl(Dev d) {
   store_partial(d, col, chunk, lane, valid, Ed, Eu);
 }
 
+#endif  // RCM_WITH_VARIANTS
+
 // ---------------------------------------------------------------------------------------------
 // Thermal RT, lbl spectra, LANE-PAIR layout (the production kernel).
 //
@@ -323,37 +329,67 @@ __device__ __forceinline__ double pair_swap(double v) {
 
 constexpr int NH = NL / 2;  // layers per lane
 
+// The recurrences in DIFFERENCE form.  The reference's L = (1-alpha)*L + alpha*B (main.cpp:307,312) with
+// alpha = 1-t is L' - B = t*(L - B): carrying X = (radiance at a level) - (Planck value of the NEXT layer on the
+// path) turns one crossing into ONE FMA whose addend does not depend on the angle,
+//     X <- t[k]*X + dB[k],   dB[k] = B[k] - B[next layer on the path],
+// and the flux sums take cw*X; the missing sum_i cw_i * B[next] is the same for every angle and is added
+// once per spectral point (pair_flux_offsets).  2 FMAs per layer crossing and angle instead of 2.5 (the
+// emission (1-t)*B per layer and angle is gone).  Positions: k = 0..9 along the lane's phase-1 direction,
+// B[10] = the partner lane's B[9] (the layer across level 10), B[-1] = 0 (nothing beyond level 0 / level 20).
+struct PairSrc {
+  double dB[NH];  // phase 1 (k = 0..9) adds dB[k] = B[k] - B[k+1]; phase 2 (k = 9..1) adds B[k] - B[k-1] = -dB[k-1]
+  double B0;      // phase 2, k = 0: B[0] - B[-1] = B[0]
+  // X0 = Linit - B[0], the radiance entering the lane's first layer (main.cpp:300-301) minus its Planck value,
+  // waits in the lane's LDS staging column (row NH) and is read once per angle: LDS reads are free beside a
+  // saturated VALU, two VGPRs are not.
+};
+
+__device__ __forceinline__ void pair_source(const double (&B)[NH], double Linit, double wsum, PairSrc &src,
+                                            double (*st)[64], int lane, double (&acc1)[NH + 1], double (&acc2)[NH]) {
+  const double Bp = pair_swap(B[NH - 1]);
+#pragma unroll
+  for (int k = 0; k < NH - 1; ++k) src.dB[k] = B[k] - B[k + 1];
+  src.dB[NH - 1] = B[NH - 1] - Bp;
+  src.B0 = B[0];
+  st[NH][lane] = Linit - B[0];
+  // what the difference form leaves out of the flux sums, for all angles at once (wsum = sum_i 2*pi*mu_i*dmu):
+  // acc1[k+1] lacks wsum*B[k+1], acc2[k] lacks wsum*B[k-1]; acc1[0] is the surface term of main.cpp:302
+  acc1[0] = fma(wsum, Linit, acc1[0]);
+#pragma unroll
+  for (int k = 1; k < NH; ++k) acc1[k] = fma(wsum, B[k], acc1[k]);
+  acc1[NH] = fma(wsum, Bp, acc1[NH]);
+#pragma unroll
+  for (int k = 1; k < NH; ++k) acc2[k] = fma(wsum, B[k - 1], acc2[k]);
+}
+
 // One angle (odd angle number m) on the lane pair, then -- while m is divisible by 3 -- the angle m/3
 // with the cubed transmissions (t_{m/3} = t_m^3).  Nested straight-line code (DEPTH levels; 3^4 = 81
 // covers nangle <= 64) instead of a loop: a loop makes the compiler carry t[] through register copies.
 template <int DEPTH>
-__device__ __forceinline__ void pair_chain(const Dev &d, const double (&t)[NH], const double (&B)[NH],
-                                           double Linit, int m, double (&acc1)[NH + 1], double (&acc2)[NH]) {
+__device__ __forceinline__ void pair_chain(const Dev &d, const double (&t)[NH], const PairSrc &src,
+                                           const double *x0, int m, double (&acc1)[NH + 1], double (&acc2)[NH]) {
   const double cw = d.ang[d.nangle + ((m - 1) >> 1)];
-  // A lane crosses each of its layers twice (phase 1 and phase 2) with the same transmission: the
-  // layer's own emission (1-t)*B = alpha*B of main.cpp:307,312 is formed once and both crossings are
-  // L = t*L + e: 5 instead of 6 instructions per layer and angle.
-  double e[NH];
+  double X = *x0;
 #pragma unroll
-  for (int k = 0; k < NH; ++k) e[k] = fma(-t[k], B[k], B[k]);
-  double L = Linit;  // its own flux contribution (main.cpp:302) is added once per band by the caller
-#pragma unroll
-  for (int k = 0; k < NH; ++k) {
-    L = fma(t[k], L, e[k]);
-    acc1[k + 1] = fma(cw, L, acc1[k + 1]);
+  for (int k = 0; k < NH; ++k) {  // main.cpp:306-309 (even lane) / :311-314 (odd lane)
+    X = fma(t[k], X, src.dB[k]);
+    acc1[k + 1] = fma(cw, X, acc1[k + 1]);
   }
-  L = pair_swap(L);  // level 10: the down radiance moves to the odd lane, the up radiance to the even lane
+  X = pair_swap(X);  // level 10: the down radiance moves to the odd lane, the up radiance to the even lane
 #pragma unroll
-  for (int k = NH - 1; k >= 0; --k) {
-    L = fma(t[k], L, e[k]);
-    acc2[k] = fma(cw, L, acc2[k]);
+  for (int k = NH - 1; k >= 1; --k) {
+    X = fma(t[k], X, -src.dB[k - 1]);
+    acc2[k] = fma(cw, X, acc2[k]);
   }
+  X = fma(t[0], X, src.B0);
+  acc2[0] = fma(cw, X, acc2[0]);
   if constexpr (DEPTH > 0) {
     if (m % 3 == 0) {
       double t3[NH];
 #pragma unroll
       for (int k = 0; k < NH; ++k) t3[k] = t[k] * t[k] * t[k];
-      pair_chain<DEPTH - 1>(d, t3, B, Linit, m / 3, acc1, acc2);
+      pair_chain<DEPTH - 1>(d, t3, src, x0, m / 3, acc1, acc2);
     }
   }
 }
@@ -372,14 +408,15 @@ __device__ __forceinline__ void pair_all_angles(const Dev &d, const double (&tau
                                                 double Linit, double (*st)[64], int lane, double (&acc1)[NH + 1],
                                                 double (&acc2)[NH]) {
   const int na = d.nangle;
-  acc1[0] = fma(d.ang[2 * na], Linit, acc1[0]);  // main.cpp:302 for all angles at once: sum_i 2*pi*mu_i*dmu * L_up
+  PairSrc src;
+  pair_source(B, Linit, d.ang[2 * na], src, st, lane, acc1, acc2);
   if constexpr (!CUBE) {
     for (int n = 2 * na - 1; n >= 1; n -= 2) {
       const double a1 = -d.ang[(n - 1) >> 1] * 0x1.71547652b82fep+0;
       double t[NH];
 #pragma unroll
       for (int k = 0; k < NH; ++k) t[k] = exp_trans(tau[k], a1);  // main.cpp:209
-      pair_chain<0>(d, t, B, Linit, n, acc1, acc2);
+      pair_chain<0>(d, t, src, &st[NH][lane], n, acc1, acc2);
     }
   } else {
     const double *sched = d.ang + 2 * na + 1;
@@ -402,7 +439,7 @@ __device__ __forceinline__ void pair_all_angles(const Dev &d, const double (&tau
           }
         }
       }
-      pair_chain<4>(d, t, B, Linit, code >> 2, acc1, acc2);
+      pair_chain<4>(d, t, src, &st[NH][lane], code >> 2, acc1, acc2);
     }
   }
 }
@@ -441,25 +478,9 @@ struct PairLds {
   double cloud[2][NH];    // grey cloud optical depth of the layer (main.cpp:266-274), 0 elsewhere
 };
 
-template <int CUBE>
-__global__ __launch_bounds__(64 * WPB, RCM_PAIR_LB) void k_rt_lbl_pair(Dev d) {
-  __shared__ PairLds s_col[WPB];
-  __shared__ double s_stage[WPB][NH + 1][64];
-  const int lane = threadIdx.x & 63;
-  const int wib = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  // work item = (chunk, column), column fastest: the waves of a block and neighbouring blocks share
-  // the chunk (its table tile stays in L2); a small ensemble still fills every wave slot
-  const long nitem = (long)d.ncol * d.nchunk;
-  const long item_raw = (long)blockIdx.x * WPB + wib;
-  const bool valid = item_raw < nitem;
-  const long item = valid ? item_raw : nitem - 1;
-  const int chunk = (int)(item / d.ncol);
-  const int col = (int)(item - (long)chunk * d.ncol);
-  const int p = lane & 1;
-  PairLds &s = s_col[wib];
-  double(*st)[64] = s_stage[wib];
-
-  // ---- column image: lanes 0..21 fill (parity, position) = (lane / 11, lane % 11)
+// Fills the LDS image of column `col` for the lane-pair lbl kernels.  Called by a whole wave.
+__device__ __forceinline__ void lbl_pair_image(const Dev &d, int col, int lane, PairLds &s) {
+  // lanes 0..21 fill (parity, position) = (lane / 11, lane % 11)
   if (lane < 2 * (NH + 1)) {
     const int q = lane / (NH + 1), k = lane - q * (NH + 1);
     const int layer = q ? NL - 1 - k : k;
@@ -480,6 +501,58 @@ __global__ __launch_bounds__(64 * WPB, RCM_PAIR_LB) void k_rt_lbl_pair(Dev d) {
     const int q = lane / NH, k = lane - q * NH;
     s.cloud[q][k] = ((q ? NL - 1 - k : k) == d.cloud_layer[col]) ? d.cloud_tau[col] : 0.0;
   }
+}
+
+// Table addressing of the lane-pair lbl kernels: one scalar base per species + a 32-bit byte offset per lane
+// (the five tables are < 4 GiB together, rcm_set_lbl_tables checks), so a load costs no vector address
+// arithmetic.  row0 = the lane's first row, rstep = the row step: layers 0,1,.. (even lane) or 19,18,.. (odd).
+struct LblAddr {
+  const char *sbase[RCM_NSPEC_LBL];
+  unsigned row0, rstep;
+};
+
+__device__ __forceinline__ LblAddr lbl_pair_addr(const Dev &d, int p) {
+  LblAddr a;
+#pragma unroll
+  for (int sp = 0; sp < RCM_NSPEC_LBL; ++sp) a.sbase[sp] = (const char *)(d.lbl_tab + (size_t)sp * NL * d.lbl_ld);
+  a.row0 = (unsigned)((p ? NL - 1 : 0) * d.lbl_ld) * 8u;
+  a.rstep = (unsigned)d.lbl_ld * 8u * (p ? -1 : 1);
+  return a;
+}
+
+// Optical depths of the lane's ten layers for the band at byte offset `off` (lbl composition, DESIGN.md 4:
+// tau = sum_s gas[s][l] * tab_s[b][l], + the grey cloud of main.cpp:266-274), clamped once, into the lane's
+// staging column st[0..9][lane].  THE optical-depth arithmetic of the production kernel; k_tau_pair dumps it.
+__device__ __forceinline__ void lbl_pair_tau(const PairLds &s, int p, const char *const (&sbase)[RCM_NSPEC_LBL],
+                                             unsigned off, unsigned rstep, double (*st)[64], int lane) {
+#pragma unroll 2
+  for (int k = 0; k < NH; ++k, off += rstep) {  // rolled: bounds the loads (and VGPRs) in flight
+    double a = 0.0;
+#pragma unroll
+    for (int sp = 0; sp < RCM_NSPEC_LBL; ++sp) a = fma(s.gas[p][sp][k], *(const double *)(sbase[sp] + off), a);
+    st[k][lane] = clamp_tau(a + s.cloud[p][k]);  // + 0.0 leaves the other layers as they are
+  }
+}
+
+template <int CUBE>
+__global__ __launch_bounds__(64 * WPB, RCM_PAIR_LB) void k_rt_lbl_pair(Dev d) {
+  __shared__ PairLds s_col[WPB];
+  __shared__ double s_stage[WPB][NH + 1][64];
+  const int lane = threadIdx.x & 63;
+  const int wib = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  // work item = (chunk, column), column fastest: the waves of a block and neighbouring blocks share
+  // the chunk (its table tile stays in L2); a small ensemble still fills every wave slot
+  const long nitem = (long)d.ncol * d.nchunk;
+  const long item_raw = (long)blockIdx.x * WPB + wib;
+  const bool valid = item_raw < nitem;
+  const long item = valid ? item_raw : nitem - 1;
+  const int chunk = (int)(item / d.ncol);
+  const int col = (int)(item - (long)chunk * d.ncol);
+  const int p = lane & 1;
+  PairLds &s = s_col[wib];
+  double(*st)[64] = s_stage[wib];
+
+  lbl_pair_image(d, col, lane, s);
   __syncthreads();
 
   // reciprocal of the column's coldest / warmest temperature (for the once-per-band Planck regime test)
@@ -500,31 +573,14 @@ __global__ __launch_bounds__(64 * WPB, RCM_PAIR_LB) void k_rt_lbl_pair(Dev d) {
 
   const long b0 = (long)chunk * d.chunk_len;
   const long b1 = min(b0 + (long)d.chunk_len, (long)d.nspec);
-  // Table addressing: one scalar base per species + a 32-bit byte offset per lane (the five tables are
-  // < 4 GiB together, rcm_set_lbl_tables checks), so a load costs no vector address arithmetic.
-  // The lane's first row and the row step: layers 0,1,.. (even) or 19,18,.. (odd).
-  const char *sbase[RCM_NSPEC_LBL];
-#pragma unroll
-  for (int sp = 0; sp < RCM_NSPEC_LBL; ++sp) sbase[sp] = (const char *)(d.lbl_tab + (size_t)sp * NL * d.lbl_ld);
-  const unsigned row0 = (unsigned)((p ? NL - 1 : 0) * d.lbl_ld) * 8u;
-  const unsigned rstep = (unsigned)d.lbl_ld * 8u * (p ? -1 : 1);
+  const LblAddr ad = lbl_pair_addr(d, p);
 
   for (long b = b0 + (lane >> 1); b < b1; b += 32) {  // main.cpp:329: 32 bands per wave pass
     // ---- optical depths of the lane's ten layers (lbl composition + cloud, main.cpp:266-274)
     double tau[NH];
-    {
-      unsigned off = row0 + (unsigned)b * 8u;
-#pragma unroll 2
-      for (int k = 0; k < NH; ++k, off += rstep) {  // rolled: bounds the loads (and VGPRs) in flight
-        double a = 0.0;
+    lbl_pair_tau(s, p, ad.sbase, ad.row0 + (unsigned)b * 8u, ad.rstep, st, lane);
 #pragma unroll
-        for (int sp = 0; sp < RCM_NSPEC_LBL; ++sp)
-          a = fma(s.gas[p][sp][k], *(const double *)(sbase[sp] + off), a);
-        st[k][lane] = clamp_tau(a + s.cloud[p][k]);  // + 0.0 leaves the other layers as they are
-      }
-#pragma unroll
-      for (int k = 0; k < NH; ++k) tau[k] = st[k][lane];
-    }
+    for (int k = 0; k < NH; ++k) tau[k] = st[k][lane];
     // ---- band Planck source of the lane's ten layers and of the surface (cplkavg.cpp:124-243)
     const double wnumhi = d.lbl_wnum[b];      // cplkavg.cpp:141
     const double wnumlo = d.lbl_wnum[b + 1];  // cplkavg.cpp:142
@@ -616,18 +672,17 @@ __device__ __forceinline__ void repwvl_pair_image(const Dev &d, int col, int lan
   }
 }
 
-// One wavelength on a lane pair: optical depths (read_tau :210-246 + cloud), monochromatic Planck
-// (main.cpp:186-204), all angles.  s = the lane's column image, st = the wave's staging column.
-template <int CUBE>
-__device__ __forceinline__ void repwvl_pair_point(const Dev &d, const RepwvlPairLds &s, int p, int w, int lane,
-                                                  double (*st)[64], double (&acc1)[NH + 1], double (&acc2)[NH]) {
+// Optical depths of the lane's ten layers at wavelength w (read_tau :210-246 + cloud, main.cpp:266-274), clamped
+// once, into the lane's staging column st[0..9][lane].  THE optical-depth arithmetic of the production repwvl
+// kernels; k_tau_pair dumps it.  s = the lane's column image.
+__device__ __forceinline__ void repwvl_pair_tau(const Dev &d, const RepwvlPairLds &s, int p, int w, double (*st)[64],
+                                                int lane) {
   // xsec[t][s][p][w]: the four corners of a bracket sit at fixed distances (next pressure: n_wvl, next
   // temperature: n_species*n_p*n_wvl), so four scalar bases + one 32-bit byte offset per (layer, species)
   // address them (the table is < 4 GiB, rcm_set_repwvl_tables checks)
   const unsigned ld8 = (unsigned)d.n_wvl * 8u, sp8 = (unsigned)d.n_p * ld8;
   const char *b00 = (const char *)d.xsec, *b01 = b00 + ld8;
   const char *b10 = b00 + (size_t)d.n_species * sp8, *b11 = b10 + ld8;
-  double tau[NH];
 #pragma unroll 1
   for (int k = 0; k < NH; ++k) {
     const unsigned vo = s.xoff[p][k] + (unsigned)w * 8u;
@@ -644,6 +699,15 @@ __device__ __forceinline__ void repwvl_pair_point(const Dev &d, const RepwvlPair
     }
     st[k][lane] = clamp_tau(a + s.cloud[p][k]);  // main.cpp:266-274; + 0.0 leaves the other layers as they are
   }
+}
+
+// One wavelength on a lane pair: optical depths, monochromatic Planck (main.cpp:186-204), all angles.
+// s = the lane's column image, st = the wave's staging column.
+template <int CUBE>
+__device__ __forceinline__ void repwvl_pair_point(const Dev &d, const RepwvlPairLds &s, int p, int w, int lane,
+                                                  double (*st)[64], double (&acc1)[NH + 1], double (&acc2)[NH]) {
+  double tau[NH];
+  repwvl_pair_tau(d, s, p, w, st, lane);
 #pragma unroll
   for (int k = 0; k < NH; ++k) tau[k] = st[k][lane];
   const double xc = d.rw_xc[w];  // h*c/(lambda*kB), main.cpp:70-72,191
@@ -762,6 +826,7 @@ __global__ __launch_bounds__(64 * WPB, RCM_PAIR_LB) void k_rt_repwvl_flat(Dev d,
   }
 }
 
+#ifdef RCM_WITH_VARIANTS
 // ---------------------------------------------------------------------------------------------
 // Thermal RT, repwvl reduced-wavelength set (one lane per wavelength: reference variants): read_tau interpolation (repwvl_thermal.cpp:197-248)
 // fused with radiative_transfer (main.cpp:320-344, monochromatic Planck main.cpp:186-204).
@@ -805,6 +870,8 @@ __global__ __launch_bounds__(64 * WPB, 2) void k_rt_repwvl(Dev d) {
   }
   store_partial(d, col, chunk, lane, valid, Ed, Eu);
 }
+
+#endif  // RCM_WITH_VARIANTS
 
 // ---------------------------------------------------------------------------------------------
 // Convective adjustment: theta = T*conv, sort descending, T = theta/conv (main.cpp:123-139,
@@ -864,7 +931,10 @@ __global__ __launch_bounds__(64 * WPB) void k_pre(Dev d, int first) {
     d.Tprev[at] = T;
   }
 #pragma unroll
-  for (int off = 16; off >= 1; off >>= 1) r = fmax(r, __shfl_xor(r, off, 64));  // lanes 0..31 cover the 20 layers
+  for (int off = 16; off >= 1; off >>= 1) {  // lanes 0..31 cover the 20 layers; a NaN layer makes the residual NaN
+    const double o = __shfl_xor(r, off, 64);  // (fmax would drop it and the column could pass for converged)
+    r = (o > r || o != o) ? o : r;
+  }
   if (on && lane == 0) d.resid[c] = first ? 1e300 : r;
   if (on && !first) {
     d.Ttau[at] = T;
@@ -1003,6 +1073,33 @@ __global__ __launch_bounds__(64) void k_tau(Dev d, int col, double *out) {
     for (int l = 0; l < NL; ++l)
       out[(size_t)p * NL + l] = lbl_tau_layer(d, s_scale, p, l, d.cloud_layer[col], d.cloud_tau[col]);
   }
+}
+
+// The optical depths AS THE PRODUCTION KERNELS FORM THEM (rcm_get_tau_production): the same column image
+// (lbl_pair_image / repwvl_pair_image: T bracket, numDens-folded corner weights) and the same per-point
+// function (lbl_pair_tau / repwvl_pair_tau: weighted-corner sum, cloud, clamp) that k_rt_lbl_pair,
+// k_rt_repwvl_pair and k_rt_repwvl_flat call, on the same lane-pair layout; one wave per 32 points.
+__global__ __launch_bounds__(64) void k_tau_pair(Dev d, int col, double *out) {
+  __shared__ union {
+    PairLds lbl;
+    RepwvlPairLds rw;
+  } img;
+  __shared__ double st[NH + 1][64];
+  const int lane = threadIdx.x, p = lane & 1;
+  if (d.mode == MODE_REPWVL)
+    repwvl_pair_image(d, col, lane, img.rw);
+  else
+    lbl_pair_image(d, col, lane, img.lbl);
+  __syncthreads();
+  const long b = (long)blockIdx.x * 32 + (lane >> 1);
+  if (b >= d.nspec) return;
+  if (d.mode == MODE_REPWVL) {
+    repwvl_pair_tau(d, img.rw, p, (int)b, st, lane);
+  } else {
+    const LblAddr ad = lbl_pair_addr(d, p);
+    lbl_pair_tau(img.lbl, p, ad.sbase, ad.row0 + (unsigned)b * 8u, ad.rstep, st, lane);
+  }
+  for (int k = 0; k < NH; ++k) out[(size_t)b * NL + (p ? NL - 1 - k : k)] = st[k][lane];
 }
 
 // doubling_adding + solar_radiative_transfer_setup (main.cpp:214-264), one thread per column:

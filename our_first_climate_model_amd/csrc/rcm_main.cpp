@@ -215,27 +215,18 @@ const char *gather(std::vector<Shard> &shards, int ncol, int nlev, std::vector<d
     const size_t blk = (size_t)per * nlev;
     std::vector<int> devs(n);
     std::vector<ncclComm_t> comms(n);
-    std::vector<hipStream_t> streams(n);
-    std::vector<double *> send(n), recv(n);
+    std::vector<double *> recv(n);
     for (int r = 0; r < n; ++r) devs[r] = shards[r].device;
     ncclck(ncclCommInitAll(comms.data(), n, devs.data()), "ncclCommInitAll");
     for (int r = 0; r < n; ++r) {
       hipck(hipSetDevice(devs[r]), "hipSetDevice");
-      hipck(hipStreamCreate(&streams[r]), "hipStreamCreate");
-      hipck(hipMalloc((void **)&send[r], blk * sizeof(double)), "hipMalloc");
       hipck(hipMalloc((void **)&recv[r], blk * n * sizeof(double)), "hipMalloc");
-      hipck(hipMemset(send[r], 0, blk * sizeof(double)), "hipMemset");
-      CK(rcm_pack_state(shards[r].h, send[r]));
-      CK(rcm_sync(shards[r].h));  // the pack runs on the handle's stream, the collective on ours
     }
+    // rcm_gather = pack + zero padding + ncclAllGather on the handle's own stream (include/rcm.h)
     ncclck(ncclGroupStart(), "ncclGroupStart");
-    for (int r = 0; r < n; ++r)
-      ncclck(ncclAllGather(send[r], recv[r], blk, ncclDouble, comms[r], streams[r]), "ncclAllGather");
+    for (int r = 0; r < n; ++r) CK(rcm_gather(shards[r].h, comms[r], recv[r], per));
     ncclck(ncclGroupEnd(), "ncclGroupEnd");
-    for (int r = 0; r < n; ++r) {
-      hipck(hipSetDevice(devs[r]), "hipSetDevice");
-      hipck(hipStreamSynchronize(streams[r]), "hipStreamSynchronize");
-    }
+    for (int r = 0; r < n; ++r) CK(rcm_sync(shards[r].h));
     std::vector<double> all(blk * n);
     hipck(hipSetDevice(devs[0]), "hipSetDevice");
     hipck(hipMemcpy(all.data(), recv[0], all.size() * sizeof(double), hipMemcpyDeviceToHost), "hipMemcpy");
@@ -243,9 +234,7 @@ const char *gather(std::vector<Shard> &shards, int ncol, int nlev, std::vector<d
       std::copy(all.begin() + r * blk, all.begin() + r * blk + (size_t)(shards[r].hi - shards[r].lo) * nlev,
                 full.begin() + (size_t)shards[r].lo * nlev);
       hipck(hipSetDevice(devs[r]), "hipSetDevice");
-      (void)hipFree(send[r]);
       (void)hipFree(recv[r]);
-      (void)hipStreamDestroy(streams[r]);
       ncclCommDestroy(comms[r]);
     }
     return "RCCL (one all-gather)";
@@ -415,7 +404,7 @@ int main(int argc, char **argv) {
       for (Shard &sh : shards) {
         r.resize(sh.hi - sh.lo);
         CK(rcm_get_residual(sh.h, r.data()));
-        for (double v : r) resid = std::max(resid, v);
+        for (double v : r) resid = (v > resid || v != v) ? v : resid;  // a NaN column is never "converged"
       }
       if (resid <= o.equilibrium) {
         write_blocks();  // the equilibrium profile

@@ -9,6 +9,14 @@ import numpy as np
 from . import api
 
 SEED = 20260104
+# Common factor on the five species amplitudes A_s of the synthetic spectra (functional form and seed of SURVEY.md
+# section 8d unchanged), chosen by bisection with the CPU oracle so that the outgoing long-wave flux E_up[0] of
+# the unperturbed fpda.lbl.atm column equals the repwvl Reduced100 value the survey recorded for the same
+# column (246.678 W/m^2; tests/golden/survey_probe.json).  With it the radiative-convective equilibrium is a
+# physical one (T_surface 297.0 K for the unperturbed column); uncalibrated (factor 1) the column is 80 W/m^2
+# too opaque and drifts to 400 K and more.  E_down[20] lands at 328.1 instead of repwvl's 354.5 W/m^2: with
+# tau ~ p_l the form has no way to concentrate the absorber near the surface as real water vapour does.
+LBL_AMP_CALIBRATION = 4.343814605552704e-3
 LBL_SPECIES = ("co2", "h2o", "o3", "ch4", "n2o")  # lbl.arts/README:5, table order of rcm_set_lbl_tables
 
 
@@ -71,11 +79,13 @@ def build_columns(atm_cols, spec, mode):
                 rel_hum=rel_hum, h2o_ref=base["vmr9"][0].copy())
 
 
-def synth_lbl_tables(n_nodes=131072, plevel=None, nlayer=20, seed=SEED, lam_lo=3000.0, lam_hi=100000.0):
+def synth_lbl_tables(n_nodes=131072, plevel=None, nlayer=20, seed=SEED, lam_lo=3000.0, lam_hi=100000.0,
+                     calibration=LBL_AMP_CALIBRATION):
     """Seeded stand-in for lbl.{co2,h2o,o3,ch4,n2o}.asc (lbl.arts/README:5-9): wavelength nodes [nm]
     log-spaced and strictly increasing, and per species a [n_nodes][nlayer] layer optical depth
     tau_s[w][l] = A_s * (p_l/1000) * 10**g_s(w), g_s a sum of Lorentzian 'lines', log10(tau) kept in
-    [-8, 4.5] (the span of the repwvl optical depths).  Returns (wvl, [5 tables])."""
+    [-8, 4.5] (the span of the repwvl optical depths); `calibration` multiplies every A_s
+    (see LBL_AMP_CALIBRATION).  Returns (wvl, [5 tables])."""
     if plevel is None:
         plevel = np.linspace(0.0, 1000.0, nlayer + 1)
     player = 0.5 * (np.asarray(plevel[:-1]) + np.asarray(plevel[1:]))
@@ -98,7 +108,7 @@ def synth_lbl_tables(n_nodes=131072, plevel=None, nlayer=20, seed=SEED, lam_lo=3
         for k in range(nlines):
             g += height[k] / (1.0 + ((x - x0[k]) / width[k]) ** 2)
         g += 0.35 * np.sin(2 * np.pi * (37 + 11 * s) * x)  # fine ripple so neighbouring nodes differ
-        logt = np.clip(g + np.log10(amp[name]), -8.0, 4.5)
+        logt = np.clip(g + np.log10(amp[name] * calibration), -8.0, 4.5)
         tab = (10.0 ** logt)[:, None] * (player[None, :] / 1000.0)
         tabs.append(np.ascontiguousarray(tab))
     return wvl, tabs

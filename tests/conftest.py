@@ -36,6 +36,15 @@ def rcm():
 
 
 @pytest.fixture(scope="session")
+def variants(rcm):
+    """The TEST-SIDE build with the one-lane-per-point reference kernels (-DRCM_WITH_VARIANTS), loaded beside
+    the product; kernel selection by RCM_EXP_VARIANT / RCM_CUBE / RCM_PLANCK_FAST / RCM_PAIR / RCM_FLAT works
+    in this library only."""
+    from our_first_climate_model_amd import build as _b
+    return rcm.load_library(_b.build_variants())
+
+
+@pytest.fixture(scope="session")
 def probe(golden):
     import json
     with open(os.path.join(golden, "survey_probe.json")) as f:

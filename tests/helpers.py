@@ -24,15 +24,9 @@ def make_inputs(pkg, mode, ncol, table="Reduced100", n_nodes=1000, perturb=True,
 
 
 def configure(e, inp):
-    c = inp["cols"]
-    e.set_grid(c["plevel"])
-    e.set_forcing(inp["solar"], inp.get("cloud_layer", 17), inp.get("cloud_tau", 1.0))
-    if inp["mode"] == "repwvl":
-        e.set_repwvl_tables(inp["table"])
-    else:
-        e.set_lbl_tables(inp["wvl"], inp["tabs"], c["h2o_ref"])
-    e.set_columns(c["Tlayer0"], c["T_surface0"], c["gas"], c["rel_hum"])
-    return e
+    """The product's own our_first_climate_model_amd.configure (duck-typed: it also drives the oracle handle)."""
+    from our_first_climate_model_amd import configure as _configure
+    return _configure(e, inp)
 
 
 def oracle_ensemble(olib, inp, threads=8, nangle=30):

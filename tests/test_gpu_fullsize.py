@@ -1,0 +1,270 @@
+"""GPU: the BASELINE.json configurations at their REAL ensemble sizes, the production optical-depth arithmetic, the
+N = 2 path with HIP compute, rcm_gather, the lbl equilibrium run.
+
+The 10 000-column launch geometries (27 spectral chunks / 67 500 blocks for lbl, 31 250 flattened repwvl waves,
+k_post over 10 000 columns, the big-ensemble branch of choose_chunks) are compared with the CPU oracle on sampled
+columns -- the oracle runs those columns alone, on identical per-column inputs, which is the same computation
+because columns are independent (no horizontal coupling anywhere in main.cpp) -- and through size-independent
+identities on EVERY column."""
+import ctypes as C
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+import helpers as H
+
+pytestmark = pytest.mark.gpu
+
+FLUX_TIGHT = 2e-9  # W/m^2 (contract: 1e-6)
+TEMP_TIGHT = 1e-9  # K     (contract: 1e-6)
+
+
+@pytest.fixture(scope="module")
+def pkg(rcm):
+    import torch
+    assert torch.cuda.is_available(), "these tests need the MI355X"
+    return rcm
+
+
+def _columns(inp, idx):
+    """The input description restricted to the columns `idx` (what the oracle runs)."""
+    idx = np.asarray(idx)
+    out = dict(inp)
+    out["ncol"] = len(idx)
+    out["cols"] = {k: (v[idx] if getattr(v, "ndim", 0) >= 1 and v.shape[0] == inp["ncol"] else v)
+                   for k, v in inp["cols"].items()}
+    return out
+
+
+def _compare_sampled(pkg, olib, inp, idx, steps):
+    g = H.gpu_ensemble(pkg, inp)
+    o = H.oracle_ensemble(olib, _columns(inp, idx))
+    g.step(steps), o.step(steps)
+    fg, fo, sg, so = g.get_fluxes(), o.get_fluxes(), g.get_state(), o.get_state()
+    for k in ("E_down", "E_up", "dE"):
+        assert H.max_abs(fg[k][idx], fo[k]) <= FLUX_TIGHT, (k, H.max_abs(fg[k][idx], fo[k]))
+    assert H.max_abs(sg["Tlayer"][idx], so["Tlayer"]) <= TEMP_TIGHT
+    assert H.max_abs(sg["T_surface"][idx], so["T_surface"]) <= TEMP_TIGHT
+    np.testing.assert_allclose(sg["timestep"][idx], so["timestep"], rtol=1e-10)
+    np.testing.assert_allclose(sg["time_h"][idx], so["time_h"], rtol=2e-7)  # float, main.cpp:359,581
+    # every column: finite, and the identities of main.cpp:337-341, 156-162, 173 between its own outputs
+    Ed, Eu, dE = fg["E_down"], fg["E_up"], fg["dE"]
+    assert np.isfinite(Ed).all() and np.isfinite(Eu).all() and np.isfinite(sg["Tlayer"]).all()
+    want = Ed[:, :-1] - Ed[:, 1:] + Eu[:, 1:] - Eu[:, :-1]
+    want[:, -1] += inp["solar"] + Ed[:, -1] - Eu[:, -1]
+    np.testing.assert_allclose(dE, want, rtol=0, atol=1e-10)
+    dt = np.minimum(5.0 / dE.max(axis=1) * (1004 * 50.0 * 100.0) / 9.80665, 43200.0)
+    np.testing.assert_allclose(sg["timestep"], dt, rtol=1e-14)
+    np.testing.assert_allclose(sg["T_surface"], sg["Tlayer"][:, -1] * inp["cols"]["conv"][-1], rtol=1e-15)
+    assert np.all(Ed[:, 0] == 0.0) and np.all(Ed[:, 1:] > 0) and np.all(Eu > 0)
+    g.close()
+    return fg, sg
+
+
+def test_config2_10000_columns_reduced100_sampled_against_oracle(pkg, olib):
+    """BASELINE configs[2] at size: 10 000 columns (CO2 x RH x T_surface perturbed) x Reduced100, 2 steps."""
+    inp = H.make_inputs(pkg, "repwvl", 10000, table="Reduced100")
+    idx = [0, 1, 2, 3, 3333, 4999, 5000, 7777, 9996, 9997, 9998, 9999]  # incl. the first and the last block
+    _compare_sampled(pkg, olib, inp, idx, steps=2)
+
+
+def test_lbl_2000_columns_big_ensemble_chunk_branch_sampled_against_oracle(pkg, olib):
+    """2 000 columns x 4 096 bands: ncol*rows > 98k, the `fill < amortised` branch of choose_chunks (16 chunks of
+    8 passes), which the 10 000-column bench launch also takes and no smaller test reaches."""
+    inp = H.make_inputs(pkg, "lbl", 2000, n_nodes=4097, atm="fpda.lbl.atm")
+    g = H.gpu_ensemble(pkg, inp)
+    assert g.get_spectral_chunks() == 16
+    g.close()
+    _compare_sampled(pkg, olib, inp, [0, 1, 999, 1000, 1998, 1999], steps=2)
+
+
+def test_config3_10000_columns_full_lbl_spectrum_sampled_against_oracle(pkg, olib):
+    """BASELINE configs[3] at size: 10 000 columns x 131 071 bands (the bench workload, same generator), 2 steps;
+    columns 0 / 4 999 / 9 999 against a 3-column oracle run (0.6 s per column-step on a core)."""
+    inp = H.make_inputs(pkg, "lbl", 10000, n_nodes=131072, atm="fpda.lbl.atm")
+    g = H.gpu_ensemble(pkg, inp)
+    assert g.get_spectral_chunks() == 27
+    g.close()
+    _compare_sampled(pkg, olib, inp, [0, 4999, 9999], steps=2)
+
+
+# ---- a5: the optical depths the PRODUCTION kernels form ------------------------------------------
+@pytest.mark.parametrize("table", ["Reduced10", "Reduced20", "Reduced100"])
+def test_production_tau_interpolation_against_read_tau(pkg, olib, table):
+    """rcm_get_tau_production runs the device functions of the production kernels (repwvl_pair_image: T bracket,
+    numDens-folded corner weights; repwvl_pair_tau: weighted-corner sum, cloud, clamp), not the side kernel k_tau
+    with the reference's corner-difference form.  Against orc_read_tau (repwvl_thermal.cpp:197-248), <= 1e-12
+    relative, for columns inside the table and for columns whose temperatures leave the table's t_ref + t_pert
+    range on either side, so that LowerPos clamps to the first / last bracket and read_tau EXTRAPOLATES
+    (repwvl_thermal.cpp:19-45: delT < 0 resp. > 1)."""
+    inp = H.make_inputs(pkg, "repwvl", 6, table=table)
+    T0 = inp["cols"]["Tlayer0"]
+    T0[2] += 140.0   # every layer above t_ref + 120: last bracket, delT up to 1.4
+    T0[3] -= 135.0   # below t_ref - 120 in most layers: first bracket, delT < 0
+    T0[4, ::2] += 150.0  # alternating: neighbouring layers in different regimes (and an unstable profile)
+    T0[5] = np.linspace(95.0, 420.0, 20)
+    g, o = H.gpu_ensemble(pkg, inp), H.oracle_ensemble(olib, inp)
+    t = inp["table"]
+    extrap = 0
+    for c in range(6):
+        tp, to = g.get_tau_production(c), o.get_tau(c)
+        np.testing.assert_allclose(tp, to, rtol=1e-12, atol=0)
+        np.testing.assert_allclose(tp, g.get_tau(c), rtol=1e-12, atol=0)
+        for l in range(20):  # count the extrapolating (column, layer) brackets the comparison covered
+            midp = 0.5 * (inp["cols"]["plevel"][l] + inp["cols"]["plevel"][l + 1]) * 100.0
+            ip = olib.orc_lower_pos(t["p_grid"].ctypes.data_as(C.POINTER(C.c_double)), t["n_p"], midp)
+            grid = t["t_ref"][ip] + t["t_pert"]
+            extrap += int(T0[c, l] < grid[0] or T0[c, l] > grid[-1])
+    assert extrap >= 40
+    # after steps the feedback has rewritten H2O and the brackets follow the new temperatures
+    g.step(3), o.step(3)
+    for c in (0, 2, 3):
+        np.testing.assert_allclose(g.get_tau_production(c), o.get_tau(c), rtol=1e-12, atol=0)
+
+
+def test_production_tau_outside_the_pressure_grid_measured_bound(pkg, olib):
+    """Layers whose mid pressure lies ABOVE the table's largest pressure (110 000 Pa): read_tau's LowerPos walks
+    the descending p_grid without a sign change and returns the LAST bracket (the 1e-3 Pa end), so delP is about
+    -1.8e8 and the 'interpolation' is a difference of nearly equal table rows times 1e8 -- the reference's own
+    result is conditioned 1e7 there (tau up to 7e6, some negative).  The two algebraically equal forms (corner
+    differences vs corner weights) then agree only to the conditioning: measured 6.4e-9 relative (Reduced100),
+    3.8e-10 (Reduced10).  Stated, not hidden: in-table layers of the same column still meet 1e-12."""
+    inp = H.make_inputs(pkg, "repwvl", 2, table="Reduced100", perturb=False)
+    inp["cols"]["plevel"] = inp["cols"]["plevel"] * 1.3  # surface at 1300 hPa: layers 17..19 leave the grid
+    g, o = H.gpu_ensemble(pkg, inp), H.oracle_ensemble(olib, inp)
+    tp, to = g.get_tau_production(0), o.get_tau(0)
+    inside = [l for l in range(20) if 0.5 * (inp["cols"]["plevel"][l] + inp["cols"]["plevel"][l + 1]) * 100 < 110000.0]
+    outside = [l for l in range(20) if l not in inside]
+    assert len(outside) >= 2
+    np.testing.assert_allclose(tp[:, inside], to[:, inside], rtol=1e-12, atol=0)
+    rel = np.abs(tp[:, outside] - np.clip(to[:, outside], -10.0, 1e7)) / np.abs(to[:, outside])
+    assert rel.max() <= 1e-7, rel.max()
+    tr = g.get_tau(0)  # the reference-form getter (k_tau): the same conditioning applies to FMA contraction
+    np.testing.assert_allclose(tr[:, inside], to[:, inside], rtol=1e-12, atol=0)
+    assert (np.abs(tr[:, outside] - to[:, outside]) / np.abs(to[:, outside])).max() <= 1e-7
+
+
+def test_production_tau_lbl_and_clamp(pkg, olib):
+    """lbl: the production composition (lbl_pair_tau) equals the oracle's; an absurd optical depth is clamped to
+    1e7 (exp(-1e7) == 0 for every angle, as exp(-1e9) is) and a NaN one stays NaN."""
+    inp = H.make_inputs(pkg, "lbl", 3, n_nodes=500, atm="fpda.lbl.atm")
+    inp["tabs"][0][7, 4] = 3e9
+    inp["tabs"][2][11, 13] = np.nan
+    g, o = H.gpu_ensemble(pkg, inp), H.oracle_ensemble(olib, inp)
+    tp, to = g.get_tau_production(1), o.get_tau(1)
+    assert tp[7, 4] == 1e7 and to[7, 4] > 1e9 and np.isnan(tp[11, 13]) and np.isnan(to[11, 13])
+    m = np.ones_like(tp, dtype=bool)
+    m[7, 4] = m[11, 13] = False
+    np.testing.assert_allclose(tp[m], to[m], rtol=1e-13, atol=0)
+
+
+def test_nan_mixing_ratio_stays_nan_and_isolated(pkg, olib):
+    """A NaN mixing ratio (or relative humidity) in one column: NaN optical depth -> NaN fluxes and temperatures
+    for that column, as in the reference arithmetic (the oracle agrees) -- not a clamped tau = -10 with finite
+    garbage; neighbours untouched; the equilibrium loop never counts the column as converged."""
+    for mode, kw in (("repwvl", dict(table="Reduced20")), ("lbl", dict(n_nodes=200, atm="fpda.lbl.atm"))):
+        inp = H.make_inputs(pkg, mode, 4, **kw)
+        inp["cols"]["gas"][2, 1, 7] = np.nan
+        g, o = H.gpu_ensemble(pkg, inp), H.oracle_ensemble(olib, inp)
+        g.step(2), o.step(2)
+        sg, so, fg = g.get_state(), o.get_state(), g.get_fluxes()
+        assert np.isnan(so["Tlayer"][2]).all()
+        assert np.isnan(sg["Tlayer"][2]).all() and np.isnan(sg["T_surface"][2]) and np.isnan(fg["E_up"][2, 0])
+        for c in (0, 1, 3):
+            assert H.max_abs(sg["Tlayer"][c], so["Tlayer"][c]) <= TEMP_TIGHT
+        n, r = g.run_to_equilibrium(1e9, 6, 3)  # every finite residual passes 1e9 K: only the NaN holds the run
+        assert n == 6 and r != r
+        assert np.isnan(g.get_residual()[2]) and np.isfinite(g.get_residual()[[0, 1, 3]]).all()
+
+
+# ---- configs[4] in small: the equilibrium criterion on the lbl path --------------------------------
+def test_lbl_run_to_equilibrium_matches_oracle(pkg, olib):
+    """rcm_run_to_equilibrium on the lbl path (calibrated synthetic spectra): GPU and oracle stop at the same
+    iteration with the same residual, and the criterion -- not the step cap -- ends the run."""
+    inp = H.make_inputs(pkg, "lbl", 4, n_nodes=600, atm="fpda.lbl.atm")
+    g, o = H.gpu_ensemble(pkg, inp), H.oracle_ensemble(olib, inp)
+    n_g, r_g = g.run_to_equilibrium(0.05, 1000, 20)
+    n_o, r_o = o.run_to_equilibrium(0.05, 1000, 20)
+    assert n_g == n_o and 100 <= n_g < 1000, (n_g, n_o)
+    assert abs(r_g - r_o) <= 1e-9 and r_g <= 0.05
+    sg, so = g.get_state(), o.get_state()
+    assert H.max_abs(sg["Tlayer"], so["Tlayer"]) <= 1e-6 and H.max_abs(sg["T_surface"], so["T_surface"]) <= 1e-6
+    assert np.all((sg["T_surface"] > 280.0) & (sg["T_surface"] < 320.0))  # a physical steady state
+
+
+# ---- multi-GPU path with HIP compute ---------------------------------------------------------------
+def _bench(args, nproc=None, timeout=900):
+    cmd = [sys.executable]
+    if nproc:
+        cmd += ["-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={nproc}", "--master-addr", "127.0.0.1",
+                "--master-port", "29631"]
+    cmd += [os.path.join(H.ROOT, "bench.py")] + args
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    return json.loads(lines[0])
+
+
+def test_two_ranks_with_hip_compute_equal_one_rank(pkg, tmp_path):
+    """bench.py as the driver launches it for N = 2 (torch.distributed.run, one process per rank; both ranks on
+    this box's only GPU, collective over gloo): shard -> HIP steps -> pack -> all-gather.  The gathered [64][21]
+    state equals the one-rank run to 1e-10 K (another cut = another fixed order of the spectral sum)."""
+    common = ["--ncol", "64", "--nodes", "4097", "--steps", "2", "--warmup", "0", "--no-cpu-baseline"]
+    one, two = str(tmp_path / "one.npy"), str(tmp_path / "two.npy")
+    d1 = _bench(common + ["--dump-state", one])
+    d2 = _bench(common + ["--gpus", "2", "--backend", "gloo", "--dump-state", two], nproc=2)
+    assert d1["n_gpus"] == 1 and d2["n_gpus"] == 2 and d2["config"]["columns_per_gpu"] == 32
+    assert d2["scaling"] == "strong" and d2["config"]["columns_total"] == 64
+    a, b = np.load(one), np.load(two)
+    assert a.shape == b.shape == (64, 21) and np.isfinite(a).all()
+    assert H.max_abs(a, b) <= 1e-10
+    assert np.ptp(a[:, 20]) > 0.1  # the perturbed columns differ: a rank-order mix-up would show
+
+
+def test_repwvl_bench_workload_contract(pkg):
+    d = _bench(["--workload", "repwvl100", "--ncol", "500", "--steps", "5", "--warmup", "1"])
+    assert d["config"]["wavelengths"] == 100 and d["roofline"]["kernel"] == "k_rt_repwvl_flat"
+    assert d["roofline"]["algorithmic_bytes_per_launch"] == (9 * 9 * 41 * 8 + 16) * 100 * 500
+    assert d["cpu_baseline"]["kind"] == "port" and d["cpu_baseline"]["single_core_rt_only_value"] > 0
+    assert d["cpu_baseline"]["single_core_reread_table_per_step_value"] < d["cpu_baseline"]["single_core_value"]
+
+
+def test_rcm_gather_one_rank_over_rccl(pkg):
+    """rcm_gather: pack + zero padding + ONE ncclAllGather on the handle's stream, with a
+    communicator the CALLER made -- here a one-rank communicator from the RCCL PyTorch loaded.  The received
+    block is the packed state followed by the padding rows."""
+    import torch
+    libdir = os.path.join(os.path.dirname(torch.__file__), "lib")
+    rccl = C.CDLL(os.path.join(libdir, "librccl.so"))
+
+    class UniqueId(C.Structure):
+        _fields_ = [("internal", C.c_char * 128)]
+
+    uid = UniqueId()
+    assert rccl.ncclGetUniqueId(C.byref(uid)) == 0
+    comm = C.c_void_p()
+    rccl.ncclCommInitRank.argtypes = [C.POINTER(C.c_void_p), C.c_int, UniqueId, C.c_int]
+    assert rccl.ncclCommInitRank(C.byref(comm), 1, uid, 0) == 0
+    try:
+        inp = H.make_inputs(pkg, "repwvl", 5, table="Reduced10")
+        g = H.gpu_ensemble(pkg, inp)
+        g.step(2)
+        recv = torch.full((8, 21), -1.0, dtype=torch.float64, device="cuda")
+        g.gather(comm.value, recv.data_ptr(), 8)
+        g.sync()
+        s = g.get_state()
+        got = recv.cpu().numpy()
+        np.testing.assert_array_equal(got[:5, :20], s["Tlayer"])
+        np.testing.assert_array_equal(got[:5, 20], s["T_surface"])
+        assert np.all(got[5:] == 0.0)
+        with pytest.raises(pkg.RcmError) as e:
+            g.gather(comm.value, recv.data_ptr(), 4)  # ncol_pad < ncol
+        assert e.value.code == -1
+    finally:
+        rccl.ncclCommDestroy.argtypes = [C.c_void_p]
+        rccl.ncclCommDestroy(comm)

@@ -114,7 +114,9 @@ def test_lbl_narrow_bands_take_the_fast_planck_path(pkg, olib):
         assert H.max_abs(fg[k], fo[k]) <= 1e-12, k  # 3 W/m^2 total, 4e-15 relative
 
 
-def test_chunking_and_kernel_variants_agree(pkg, olib, monkeypatch):
+def test_chunking_and_kernel_variants_agree(pkg, olib, variants, monkeypatch):
+    # the reference-variant kernels live in the TEST-SIDE build (tests/_variants, -DRCM_WITH_VARIANTS); the last
+    # tuple is the production kernel of that same build
     inp = H.make_inputs(pkg, "lbl", 3, n_nodes=1500, atm="fpda.lbl.atm")
     o = H.oracle_ensemble(olib, inp)
     o.step(2)
@@ -123,7 +125,7 @@ def test_chunking_and_kernel_variants_agree(pkg, olib, monkeypatch):
         monkeypatch.setenv("RCM_EXP_VARIANT", str(expv))
         monkeypatch.setenv("RCM_CUBE", str(cube))
         monkeypatch.setenv("RCM_PLANCK_FAST", str(plk))
-        g = H.gpu_ensemble(pkg, inp)
+        g = H.gpu_ensemble(pkg, inp, library=variants)
         g.set_spectral_chunks(chunks)
         g.step(2)
         fg = g.get_fluxes()
@@ -568,7 +570,7 @@ def test_other_angle_counts(pkg, olib, nangle):
         _check_state(g, o)
 
 
-def test_repwvl_kernel_variants_agree(pkg, olib, monkeypatch):
+def test_repwvl_kernel_variants_agree(pkg, olib, variants, monkeypatch):
     # the lane-per-wavelength reference kernels (library exp, no cube chains, no lane pairs) and the
     # production lane-pair kernel all against the oracle
     inp = H.make_inputs(pkg, "repwvl", 5, table="Reduced100")
@@ -579,7 +581,7 @@ def test_repwvl_kernel_variants_agree(pkg, olib, monkeypatch):
         monkeypatch.setenv("RCM_EXP_VARIANT", str(expv))
         monkeypatch.setenv("RCM_CUBE", str(cube))
         monkeypatch.setenv("RCM_PAIR", str(pair))
-        g = H.gpu_ensemble(pkg, inp)
+        g = H.gpu_ensemble(pkg, inp, library=variants)
         g.set_spectral_chunks(chunks)
         g.step(3)
         fg, sg = g.get_fluxes(), g.get_state()
@@ -590,7 +592,7 @@ def test_repwvl_kernel_variants_agree(pkg, olib, monkeypatch):
 
 
 @pytest.mark.parametrize("table", ["Reduced10", "Reduced20", "Reduced100"])
-def test_flattened_repwvl_kernel_segment_boundaries(pkg, olib, table, monkeypatch):
+def test_flattened_repwvl_kernel_segment_boundaries(pkg, olib, variants, table, monkeypatch):
     # k_rt_repwvl_flat: a wave's 32 items straddle 2..5 columns; every ensemble size shifts the boundaries
     for ncol in (1, 2, 3, 5, 33):
         inp = H.make_inputs(pkg, "repwvl", ncol, table=table)
@@ -599,7 +601,7 @@ def test_flattened_repwvl_kernel_segment_boundaries(pkg, olib, table, monkeypatc
         res = []
         for flat in ("1", "0"):
             monkeypatch.setenv("RCM_FLAT", flat)
-            g = H.gpu_ensemble(pkg, inp)
+            g = H.gpu_ensemble(pkg, inp, library=None if flat == "1" else variants)  # "1": the product itself
             g.step(2)
             _check_fluxes(g, o)
             _check_state(g, o, 1e-9)

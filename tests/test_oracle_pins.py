@@ -210,7 +210,7 @@ def test_library_exports_every_declared_symbol(rcm):
     L = rcm.lib()
     for n in sorted(names):
         assert hasattr(L, n), f"{n} declared in include/rcm.h but not exported"
-    assert L.rcm_abi_version() == 1
+    assert L.rcm_abi_version() == 2
 
 
 def test_no_gpu_means_loud_failure_not_fallback(rcm):
