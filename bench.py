@@ -279,12 +279,15 @@ def main():
         np.save(args.dump_state, final.cpu().numpy())
 
     if rank == 0:
-        rt_avg_s = rt_ms / 1e3 / max(rt_n, 1)
+        # per STEP: the lbl path launches its RT kernel once per step; the fused repwvl kernel (k_step_repwvl) covers
+        # all K steps in rt_n launches, so the HIP-event time is divided by the steps it covers
+        rt_avg_s = rt_ms / 1e3 / args.steps
         per_point = BYTES_PER_BAND if lbl else BYTES_PER_RWVL
-        alg_bytes = per_point * nspec * ncol_local  # per RT launch on this rank
+        alg_bytes = per_point * nspec * ncol_local  # per step on this rank
         achieved = alg_bytes / rt_avg_s / 1e9
         tag = "r02_lbl" if lbl else "r02_repwvl100"
-        kern = "k_rt_lbl_pair" if lbl else "k_rt_repwvl_flat"
+        fused = (not lbl) and ens.get_step_fusion() > 0
+        kern = "k_rt_lbl_pair" if lbl else ("k_step_repwvl" if fused else "k_rt_repwvl_flat")
         valu, pmc = valu_issue(tag, kern, nspec * ncol_local, rt_avg_s)
         # HBM bytes per launch from the PMC passes committed under profiles/ (2 x FETCH_SIZE + WRITE_SIZE, the
         # gfx950 correction of MI355X_MICROARCH.md's HBM section); only valid for the workload they were collected on
@@ -312,7 +315,9 @@ def main():
                       "perturbations": "CO2 x linspace(0.5,4)"}
             note = ("numerator = 26 584 B per (column, wavelength): the xsec table slice + (lambda, weight), as if "
                     "every column read the table itself (SURVEY 8d); the 2.66 MB table lives in L2, the kernel is "
-                    "fp64-VALU-issue bound (profiles/README.md)")
+                    "fp64-VALU-issue bound (profiles/README.md); avg_launch_ms and algorithmic_bytes_per_launch are "
+                    "per STEP: the fused kernel k_step_repwvl runs steps_per_launch iterations per launch and its "
+                    "time includes adjustment, feedback and time step (there is no separate kernel for them)")
         config["parallelism"] = f"columns sharded over {world} GPU(s), one all-gather at the end"
         out = {
             "metric": "column_timesteps_per_sec", "value": ncol_total * args.steps / elapsed,
@@ -322,7 +327,8 @@ def main():
             "roofline": {"bound": "hbm", "actual_bound": "fp64_valu_issue", "kernel": kern, "achieved": achieved,
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "traffic_source": traffic_src, "algorithmic_bytes_per_launch": alg_bytes,
-                         "avg_launch_ms": rt_avg_s * 1e3, "launches": rt_n, "fp64_valu_issue": valu, "note": note},
+                         "avg_launch_ms": rt_avg_s * 1e3, "launches": rt_n, "steps_per_launch": args.steps / max(rt_n, 1),
+                         "fp64_valu_issue": valu, "note": note},
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(pkg, inp, args.workload, log)

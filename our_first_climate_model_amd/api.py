@@ -67,6 +67,8 @@ def _configure(L):
     L.rcm_pack_state.argtypes = [vp, vp]
     L.rcm_set_spectral_chunks.argtypes = [vp, C.c_int]
     L.rcm_get_spectral_chunks.argtypes = [vp]
+    L.rcm_set_step_fusion.argtypes = [vp, C.c_int]
+    L.rcm_get_step_fusion.argtypes = [vp]
     L.rcm_set_rt_timing.argtypes = [vp, C.c_int]
     L.rcm_get_rt_timing.argtypes = [vp, _dp, _ip]
     L.rcm_atm_load.argtypes = [C.c_char_p, C.c_int, _dp, _ip, _ip]
@@ -373,6 +375,16 @@ class Ensemble:
 
     def get_spectral_chunks(self):
         n = self._L.rcm_get_spectral_chunks(self.h)
+        if n < 0:
+            self._ck(n)
+        return n
+
+    def set_step_fusion(self, mode):
+        """repwvl whole-step kernel: -1 automatic, 0 never, 1 always (rcm_set_step_fusion)."""
+        self._ck(self._L.rcm_set_step_fusion(self.h, mode))
+
+    def get_step_fusion(self):
+        n = self._L.rcm_get_step_fusion(self.h)
         if n < 0:
             self._ck(n)
         return n

@@ -41,6 +41,7 @@ struct rcm_ensemble {
   bool have_grid = false, have_columns = false;
   long long step_index = 0;  // the reference's loop variable i (main.cpp:531)
   int user_chunks = 0;
+  int fusion = -1;  // repwvl whole-step kernel k_step_repwvl: -1 automatic, 0 never, 1 always
   int exp_variant = 1, cube = 1, planck_fast = 1, pair = 1, flat = 1;
   std::vector<double> plevel, player, conv;
   std::vector<void *> allocs;
@@ -156,6 +157,28 @@ bool use_flat(const rcm_ensemble *h) {
          h->d.n_wvl >= 8;  // at most 31/8 + 2 = 5 column images per wave
 }
 
+// The fused whole-step kernel of the repwvl path (k_step_repwvl): lane pairs per column LPC (a power of two, K =
+// 32/LPC columns per wave).  Cost model in wave passes per SIMD: a wave runs ceil(n_wvl/LPC) passes (+ ~1 for the
+// phases around them), ceil(ncol/K) waves share 1024 SIMDs.  10 000 x 100: LPC 16 (5 000 waves x 7 passes = 35
+// per SIMD against 30.5 for perfect packing; 32: 40, 8: 39).  Returns 0 when the three-kernel path should run:
+// fewer than two waves per SIMD would leave the chip to latency (small ensembles keep the flattened kernel,
+// which cuts the work into 32-item waves).
+int choose_lpc(const rcm_ensemble *h) {
+  if (h->mode != rcm::MODE_REPWVL || !h->pair || h->exp_variant != 1 || h->user_chunks != 0 || h->fusion == 0) return 0;
+  int best = 0;
+  double best_cost = 1e300;
+  for (int lpc = 32; lpc >= 2; lpc >>= 1) {
+    const int K = 32 / lpc;
+    const long waves = ((long)h->ncol + K - 1) / K;
+    const long passes = (h->d.n_wvl + lpc - 1) / lpc;
+    const double cost = (double)((waves + 1023) / 1024) * (double)(passes + 1);
+    if (cost < best_cost) best_cost = cost, best = lpc;
+  }
+  if (h->fusion == 1) return best;
+  const int K = 32 / best;
+  return ((long)h->ncol + K - 1) / K >= 2048 ? best : 0;
+}
+
 int ensure_partials(rcm_ensemble *h) {
   if (use_flat(h)) {
     h->d.nchunk = (h->d.n_wvl + 31) / 32 + 1;  // record slots per column, see k_rt_repwvl_flat
@@ -239,26 +262,75 @@ void launch_rt(rcm_ensemble *h, int blocks) {
   launch_rt_pair<1>(h, blocks);
 }
 
+template <int CUBE, int LPC>
+void launch_fused_lpc(rcm_ensemble *h, int first, int nsteps) {
+  constexpr int K = 32 / LPC;
+  const size_t lds = (size_t)K * (sizeof(rcm::RepwvlPairLds) + sizeof(rcm::StepLds)) + (size_t)(rcm::NH + 1) * 64 * sizeof(double) +
+                     (K * 102 <= (rcm::NH + 1) * 64 ? 0 : (size_t)K * 102 * sizeof(double));
+  const auto kern = rcm::k_step_repwvl<CUBE, LPC>;
+  if (lds > 48 * 1024)
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  hipLaunchKernelGGL(kern, dim3((unsigned)((h->ncol + K - 1) / K)), dim3(64), lds, h->stream, h->d, first, nsteps);
+}
+
+template <int CUBE>
+void launch_fused(rcm_ensemble *h, int lpc, int first, int nsteps) {
+  switch (lpc) {
+    case 32: launch_fused_lpc<CUBE, 32>(h, first, nsteps); break;
+    case 16: launch_fused_lpc<CUBE, 16>(h, first, nsteps); break;
+    case 8: launch_fused_lpc<CUBE, 8>(h, first, nsteps); break;
+    case 4: launch_fused_lpc<CUBE, 4>(h, first, nsteps); break;
+    default: launch_fused_lpc<CUBE, 2>(h, first, nsteps); break;
+  }
+}
+
+int timing_begin(rcm_ensemble *h, hipEvent_t *e1) {
+  *e1 = nullptr;
+  if (!h->timing) return RCM_OK;
+  if (h->events_used == h->events.size()) {
+    hipEvent_t a, b;
+    HIPCK(hipEventCreate(&a));
+    HIPCK(hipEventCreate(&b));
+    h->events.emplace_back(a, b);
+  }
+  const hipEvent_t e0 = h->events[h->events_used].first;
+  *e1 = h->events[h->events_used].second;
+  ++h->events_used;
+  HIPCK(hipEventRecord(e0, h->stream));
+  return RCM_OK;
+}
+
+// `nsteps` iterations of the repwvl path in ONE launch (k_step_repwvl); long runs are cut into launches of at most
+// 512 iterations so that no kernel runs for more than a few seconds.
+int launch_fused_steps(rcm_ensemble *h, int lpc, int nsteps) {
+  while (nsteps > 0) {
+    const int n = nsteps < 512 ? nsteps : 512;
+    const int first = (h->step_index == 0) ? 1 : 0;
+    hipEvent_t e1 = nullptr;
+    if (int rc = timing_begin(h, &e1)) return rc;
+#ifdef RCM_WITH_VARIANTS
+    if (!h->cube)
+      launch_fused<0>(h, lpc, first, n);
+    else
+#endif
+      launch_fused<1>(h, lpc, first, n);
+    if (e1) HIPCK(hipEventRecord(e1, h->stream));
+    HIPCK(hipGetLastError());
+    h->step_index += n;
+    nsteps -= n;
+  }
+  return RCM_OK;
+}
+
 int launch_step(rcm_ensemble *h) {
   Dev &d = h->d;
   const int first = (h->step_index == 0) ? 1 : 0;
   hipLaunchKernelGGL(rcm::k_pre, dim3((h->ncol + rcm::WPB - 1) / rcm::WPB), dim3(64 * rcm::WPB), 0, h->stream, d, first);
   const int blocks = (int)(((long)h->ncol * d.nchunk + rcm::WPB - 1) / rcm::WPB);
-  hipEvent_t e0 = nullptr, e1 = nullptr;
-  if (h->timing) {
-    if (h->events_used == h->events.size()) {
-      hipEvent_t a, b;
-      HIPCK(hipEventCreate(&a));
-      HIPCK(hipEventCreate(&b));
-      h->events.emplace_back(a, b);
-    }
-    e0 = h->events[h->events_used].first;
-    e1 = h->events[h->events_used].second;
-    ++h->events_used;
-    HIPCK(hipEventRecord(e0, h->stream));
-  }
+  hipEvent_t e1 = nullptr;
+  if (int rc = timing_begin(h, &e1)) return rc;
   launch_rt(h, blocks);
-  if (h->timing) HIPCK(hipEventRecord(e1, h->stream));
+  if (e1) HIPCK(hipEventRecord(e1, h->stream));
   Dev dp = d;  // what k_post sums: the chunk records, or their slice sums
   if (h->slice_buf) {
     const int len = (d.nchunk + kPostSlices - 1) / kPostSlices;
@@ -679,11 +751,23 @@ int rcm_step(rcm_ensemble *h, int nsteps) {
   if (h->mode == rcm::MODE_NONE || !h->have_grid || !h->have_columns)
     return fail(RCM_ERR_STATE, "rcm_step: grid, spectral tables and columns must be set first");
   if (int rc = use_device(h)) return rc;
+  if (const int lpc = choose_lpc(h)) return launch_fused_steps(h, lpc, nsteps);
   if (!h->d.partial)
     if (int rc = ensure_partials(h)) return rc;
   for (int i = 0; i < nsteps; ++i)
     if (int rc = launch_step(h)) return rc;
   return RCM_OK;
+}
+
+int rcm_set_step_fusion(rcm_ensemble *h, int mode) {
+  if (!h || mode < -1 || mode > 1) return fail(RCM_ERR_ARG, "rcm_set_step_fusion: mode must be -1 (automatic), 0 or 1");
+  h->fusion = mode;
+  return RCM_OK;
+}
+
+int rcm_get_step_fusion(rcm_ensemble *h) {
+  if (!h || h->mode == rcm::MODE_NONE) return fail(RCM_ERR_STATE, "rcm_get_step_fusion: tables not set");
+  return choose_lpc(h);
 }
 
 int rcm_sync(rcm_ensemble *h) {

@@ -33,13 +33,15 @@ __device__ __forceinline__ double clamp_tau(double tau) {
 }
 
 #ifndef RCM_EXP_DEG
-#define RCM_EXP_DEG 7  // polynomial of the transmissions' 2^f (c0 = 1 exactly), max rel err of t:
-                       //   7 (default): degree 7 for 2^(f/2), then one squaring -> 7.4e-13   (12 VALU instructions)
-                       //   8 -> 2.1e-12, 9 -> 3.7e-14, 10 -> 5.8e-16 on the full range     (12 / 13 / 14)
-                       // Flux error of the kernel against a long-double evaluation of the reference's sweep
-                       // (tools/accuracy_vs_longdouble.py, 19 999 bands): degree 10 1.6e-13, 9 4.3e-13, 7-half
-                       // 7e-13, 8 2.0e-11 W/m^2; the CPU reference itself: 2e-11.  The contract is 1e-6 W/m^2.
+#define RCM_EXP_DEG 7  // degree of the polynomial of the transmissions (c0 = 1 exactly), and
 #endif
+#ifndef RCM_EXP_HALF
+#define RCM_EXP_HALF 1  // 1: the polynomial is 2^(f/2) and the result is squared; 0: 2^f on the full range.
+#endif                  // VALU instructions and max rel err of t:
+                        //   half, degree 7 (default) 12, 7.4e-13;  half 8: 13, 1.5e-14;  half 6: 11, 6.8e-11
+                        //   full, degree 8: 12, 2.1e-12;  9: 13, 3.7e-14;  10: 14, 5.8e-16
+                        // Flux error of the kernel against a long-double evaluation of the reference's sweep
+                        // (tools/accuracy_vs_longdouble.py): profiles/README.md; the contract is 1e-6 W/m^2.
 __device__ __forceinline__ double exp_trans(double tau, double a1) {
   constexpr double kMagic = 0x1.8p+52;
   const double z = fma(tau, a1, kMagic);  // low word of z = k = rint(-tau*s*log2e), two's complement
@@ -47,10 +49,18 @@ __device__ __forceinline__ double exp_trans(double tau, double a1) {
   // f = y - k with y = tau*a1 = -tau*s*log2(e): one FMA, exact up to the rounding of a1
   // (relative 1.1e-16 of y: <= 4e-15 of the result wherever t >= 1e-15)
   const double f = fma(tau, a1, -kf);
-#if RCM_EXP_DEG == 7
-  double q = kExp2Half7[7];  // 2^(f/2): the halving is folded into the coefficients
+#if RCM_EXP_HALF  // 2^(f/2), the halving folded into the coefficients, then one squaring
+#if RCM_EXP_DEG == 6
+  constexpr const double(&c)[7] = kExp2Half6;
+#elif RCM_EXP_DEG == 7
+  constexpr const double(&c)[8] = kExp2Half7;
+#else
+  constexpr const double(&c)[9] = kExp2Half8;
+#endif
+  constexpr int deg = sizeof(c) / sizeof(double) - 1;
+  double q = c[deg];
 #pragma unroll
-  for (int i = 6; i >= 0; --i) q = fma(q, f, kExp2Half7[i]);
+  for (int i = deg - 1; i >= 0; --i) q = fma(q, f, c[i]);
   q *= q;
 #elif RCM_EXP_DEG == 8
   double q = kExp2Poly8[8];

@@ -42,6 +42,9 @@ constexpr int WPB = 4;       // waves per block = columns per block (one per SIM
 #ifndef RCM_PLK_UNROLL
 #define RCM_PLK_UNROLL 1  // independent band-Planck evaluations in flight
 #endif
+#ifndef RCM_SWEEP_DIFF
+#define RCM_SWEEP_DIFF 1  // recurrences of the lane-pair kernels in difference form (2 FMAs per crossing and angle);
+#endif                    // 0: the emission form L = t*L + (1-t)*B (2.5), kept for A/B runs
 
 enum { MODE_NONE = -1, MODE_REPWVL = 0, MODE_LBL = 1 };
 
@@ -347,6 +350,8 @@ struct PairSrc {
 
 __device__ __forceinline__ void pair_source(const double (&B)[NH], double Linit, double wsum, PairSrc &src,
                                             double (*st)[64], int lane, double (&acc1)[NH + 1], double (&acc2)[NH]) {
+  acc1[0] = fma(wsum, Linit, acc1[0]);  // the surface term of main.cpp:302, all angles at once
+#if RCM_SWEEP_DIFF
   const double Bp = pair_swap(B[NH - 1]);
 #pragma unroll
   for (int k = 0; k < NH - 1; ++k) src.dB[k] = B[k] - B[k + 1];
@@ -354,13 +359,18 @@ __device__ __forceinline__ void pair_source(const double (&B)[NH], double Linit,
   src.B0 = B[0];
   st[NH][lane] = Linit - B[0];
   // what the difference form leaves out of the flux sums, for all angles at once (wsum = sum_i 2*pi*mu_i*dmu):
-  // acc1[k+1] lacks wsum*B[k+1], acc2[k] lacks wsum*B[k-1]; acc1[0] is the surface term of main.cpp:302
-  acc1[0] = fma(wsum, Linit, acc1[0]);
+  // acc1[k+1] lacks wsum*B[k+1], acc2[k] lacks wsum*B[k-1]
 #pragma unroll
   for (int k = 1; k < NH; ++k) acc1[k] = fma(wsum, B[k], acc1[k]);
   acc1[NH] = fma(wsum, Bp, acc1[NH]);
 #pragma unroll
   for (int k = 1; k < NH; ++k) acc2[k] = fma(wsum, B[k - 1], acc2[k]);
+#else
+#pragma unroll
+  for (int k = 0; k < NH; ++k) src.dB[k] = B[k];  // the emission form keeps the Planck values themselves
+  src.B0 = 0.0;
+  st[NH][lane] = Linit;
+#endif
 }
 
 // One angle (odd angle number m) on the lane pair, then -- while m is divisible by 3 -- the angle m/3
@@ -371,6 +381,7 @@ __device__ __forceinline__ void pair_chain(const Dev &d, const double (&t)[NH], 
                                            const double *x0, int m, double (&acc1)[NH + 1], double (&acc2)[NH]) {
   const double cw = d.ang[d.nangle + ((m - 1) >> 1)];
   double X = *x0;
+#if RCM_SWEEP_DIFF
 #pragma unroll
   for (int k = 0; k < NH; ++k) {  // main.cpp:306-309 (even lane) / :311-314 (odd lane)
     X = fma(t[k], X, src.dB[k]);
@@ -384,6 +395,24 @@ __device__ __forceinline__ void pair_chain(const Dev &d, const double (&t)[NH], 
   }
   X = fma(t[0], X, src.B0);
   acc2[0] = fma(cw, X, acc2[0]);
+#else
+  // emission form: the layer's own emission (1-t)*B = alpha*B of main.cpp:307,312 is formed once per layer and
+  // angle and both crossings are L = t*L + e
+  double e[NH];
+#pragma unroll
+  for (int k = 0; k < NH; ++k) e[k] = fma(-t[k], src.dB[k], src.dB[k]);
+#pragma unroll
+  for (int k = 0; k < NH; ++k) {
+    X = fma(t[k], X, e[k]);
+    acc1[k + 1] = fma(cw, X, acc1[k + 1]);
+  }
+  X = pair_swap(X);
+#pragma unroll
+  for (int k = NH - 1; k >= 0; --k) {
+    X = fma(t[k], X, e[k]);
+    acc2[k] = fma(cw, X, acc2[k]);
+  }
+#endif
   if constexpr (DEPTH > 0) {
     if (m % 3 == 0) {
       double t3[NH];
@@ -640,17 +669,21 @@ struct RepwvlPairLds {
 
 // Fills the LDS image of column `col`: per (parity, position) the temperature bracket of read_tau
 // (repwvl_thermal.cpp:229-239), the layer constants, the mixing ratios.  Called by a whole wave.
-__device__ __forceinline__ void repwvl_pair_image(const Dev &d, int col, int lane, RepwvlPairLds &s) {
+// Tl / Ttau [NL], Tsfc and h2o [NL] (species 0, the row the feedback rewrites) come from the caller: the
+// column's rows in HBM, or the copies a fused step keeps in LDS.
+__device__ __forceinline__ void repwvl_pair_image_from(const Dev &d, int col, int lane, RepwvlPairLds &s,
+                                                       const double *Tl, const double *Ttau, double Tsfc,
+                                                       const double *h2o) {
   if (lane < 2 * (NH + 1)) {
     const int q = lane / (NH + 1), k = lane - q * (NH + 1);
     if (k == NH) {
-      s.T[q][k] = d.Tsfc[col];
-      s.rT[q][k] = 1.0 / d.Tsfc[col];
+      s.T[q][k] = Tsfc;
+      s.rT[q][k] = 1.0 / Tsfc;
     } else {
       const int layer = q ? NL - 1 - k : k;
-      s.T[q][k] = d.T[(size_t)col * NL + layer];
+      s.T[q][k] = Tl[layer];
       s.rT[q][k] = 1.0 / s.T[q][k];
-      const double midT = d.Ttau[(size_t)col * NL + layer];  // :217 (prop_at_Lev == 0)
+      const double midT = Ttau[layer];  // :217 (prop_at_Lev == 0)
       const int ip = d.ip[layer];
       const double tr = d.t_ref[ip];
       const double *tp = d.t_pert;
@@ -668,8 +701,13 @@ __device__ __forceinline__ void repwvl_pair_image(const Dev &d, int col, int lan
     const int q = i / (RCM_NSPEC_REPWVL * NH), r = i - q * (RCM_NSPEC_REPWVL * NH);
     const int sp = r / NH, k = r - sp * NH;
     const int layer = q ? NL - 1 - k : k;
-    s.vmr[q][sp][k] = d.gas[((size_t)col * RCM_NSPEC_REPWVL + sp) * NL + layer];
+    s.vmr[q][sp][k] = sp == 0 ? h2o[layer] : d.gas[((size_t)col * RCM_NSPEC_REPWVL + sp) * NL + layer];
   }
+}
+
+__device__ __forceinline__ void repwvl_pair_image(const Dev &d, int col, int lane, RepwvlPairLds &s) {
+  repwvl_pair_image_from(d, col, lane, s, d.T + (size_t)col * NL, d.Ttau + (size_t)col * NL, d.Tsfc[col],
+                         d.gas + (size_t)col * RCM_NSPEC_REPWVL * NL);
 }
 
 // Optical depths of the lane's ten layers at wavelength w (read_tau :210-246 + cloud, main.cpp:266-274), clamped
@@ -872,6 +910,198 @@ __global__ __launch_bounds__(64 * WPB, 2) void k_rt_repwvl(Dev d) {
 }
 
 #endif  // RCM_WITH_VARIANTS
+
+// ---------------------------------------------------------------------------------------------
+// THE WHOLE TIME-LOOP BODY main.cpp:531-583 FOR THE repwvl PATH IN ONE KERNEL (big ensembles).
+//
+// A wave OWNS K = 32/LPC columns for the whole launch and runs `nsteps` iterations on them without leaving the
+// kernel: columns are independent (no horizontal coupling anywhere in main.cpp), so nothing but the wave itself
+// ever waits for a column's previous step.  Per iteration:
+//   A  convective adjustment (rank sort of theta over 20 lanes per column, main.cpp:536-540), equilibrium
+//      residual, water-vapour feedback (main.cpp:281-289)                                   [k_pre's work]
+//   B  the column images of read_tau (T brackets, corner weights; repwvl_thermal.cpp:229-239)
+//   C  radiative transfer (main.cpp:320-344): LPC lane pairs per column, lane pair j of a column takes the
+//      wavelengths j, j+LPC, ..; a lane never changes column, so its 21 flux sums stay in VGPRs for all passes
+//   D  butterfly over the column's LPC lane pairs -> E_down[21], E_up[21]
+//   E  dE, time step, temperature update, time (main.cpp:337-341, 156-176, 581)            [k_post's work]
+// Against k_pre + k_rt_repwvl_flat + k_post: no per-32-item column images, no segmented reduction through LDS, no
+// partial records in HBM, no launch boundaries (3 per step), and the latency-bound phases A, B, D, E of one wave
+// overlap the VALU-bound phase C of its neighbours instead of running in lock-step at every kernel start.
+// State flows through LDS from one iteration to the next; HBM holds the same arrays as ever for the getters.
+// One wave per block: waves of a block would only wait for each other.
+// ---------------------------------------------------------------------------------------------
+struct StepLds {     // per owned column
+  double T[NL];      // Tlayer as the last thermodynamics left it (main.cpp:583)
+  double Ttau[NL];   // temperatures the optical depths are interpolated at (main.cpp:500 / :564)
+  double Tprev[NL];  // adjusted profile of the previous iteration (equilibrium residual)
+  double h2o[NL];    // H2O mixing ratio (the row the feedback rewrites)
+  double Tsfc;
+  float time_h;      // the column's clock (a float, main.cpp:359)
+};
+
+template <int CUBE, int LPC>
+__global__ __launch_bounds__(64, RCM_PAIR_LB) void k_step_repwvl(Dev d, int first_step, int nsteps) {
+  constexpr int K = 32 / LPC;  // columns per wave
+  extern __shared__ __align__(16) unsigned char s_dyn[];
+  RepwvlPairLds *img = reinterpret_cast<RepwvlPairLds *>(s_dyn);
+  StepLds *stp = reinterpret_cast<StepLds *>(s_dyn + K * sizeof(RepwvlPairLds));
+  double(*st)[64] = reinterpret_cast<double(*)[64]>(s_dyn + K * (sizeof(RepwvlPairLds) + sizeof(StepLds)));
+  // scratch of phases A, D and E: per column theta[20] (later dE), sorted[20], E_down[21] + E_up[21] (in phase A:
+  // the residuals) = 102 doubles, aliased onto the staging columns, which are only busy in phase C
+  // (K * 102 <= 11 * 64 holds for K <= 6; more columns per wave get their own block behind st)
+  double *scr = (K * 102 <= (NH + 1) * 64) ? &st[0][0] : reinterpret_cast<double *>(st + (NH + 1));
+  const int lane = threadIdx.x;
+  const int c0 = blockIdx.x * K;
+  const int p = lane & 1;
+  const int slot = (lane >> 1) / LPC;       // which of the wave's columns this lane pair works for
+  const int j = (lane >> 1) - slot * LPC;   // its index among the column's lane pairs
+  const bool col_ok = c0 + slot < d.ncol;
+  // lanes of phases A / E: (column q, layer l), three columns per round
+  const int aq = lane / NL, al = lane - aq * NL;
+
+  // ---- load the owned columns' state
+  for (int i = lane; i < K * NL; i += 64) {
+    const int q = i / NL, l = i - q * NL, c = min(c0 + q, d.ncol - 1);
+    stp[q].T[l] = d.T[(size_t)c * NL + l];
+    stp[q].Ttau[l] = d.Ttau[(size_t)c * NL + l];
+    stp[q].Tprev[l] = d.Tprev[(size_t)c * NL + l];
+    stp[q].h2o[l] = d.gas[(size_t)c * RCM_NSPEC_REPWVL * NL + l];
+    if (l == 0) {
+      stp[q].Tsfc = d.Tsfc[c];
+      stp[q].time_h = d.time_h[c];
+    }
+  }
+  __syncthreads();
+
+  for (int step = 0; step < nsteps; ++step) {
+    const bool first = first_step && step == 0;
+    // ================= A: adjustment, residual, feedback (main.cpp:536-572) =================
+    for (int base = 0; base < K; base += 3) {
+      const int q = base + aq;
+      const bool on = lane < 3 * NL && q < K && c0 + q < d.ncol;
+      double *th = scr + (size_t)(on ? q : 0) * 102, *sorted = th + NL, *rr = th + 2 * NL;
+      double T = 0.0, thv = 0.0, conv = 1.0;
+      if (on) {
+        T = stp[q].T[al];
+        conv = d.conv[al];
+        if (first) stp[q].Ttau[al] = T;  // main.cpp:500: the first optical depths come from the pre-adjustment profile
+        thv = T * conv;                  // t_to_theta, main.cpp:123-129
+        th[al] = thv;
+        sorted[al] = __builtin_nan("");  // a NaN among the inputs leaves ranks unassigned: the column stays NaN
+      }
+      __syncthreads();
+      if (on) {
+        int rank = 0;
+        for (int i = 0; i < NL; ++i) {
+          const double ti = th[i];
+          rank += (ti > thv) || (ti == thv && i < al);
+        }
+        sorted[rank] = thv;  // sort(theta, greater), main.cpp:538
+      }
+      __syncthreads();
+      if (on) {
+        T = sorted[al] / conv;  // theta_to_t, main.cpp:131-139
+        rr[al] = fabs(T - stp[q].Tprev[al]);
+        stp[q].Tprev[al] = T;
+        stp[q].T[al] = T;
+        const size_t at = (size_t)(c0 + q) * NL + al;
+        d.Tprev[at] = T;
+        if (!first) {
+          stp[q].Ttau[al] = T;
+          const double vmr = d.rel_hum[at] * magnus_dev(T) / d.player[al];  // main.cpp:285-286
+          stp[q].h2o[al] = vmr;
+          d.gas[(size_t)(c0 + q) * RCM_NSPEC_REPWVL * NL + al] = vmr;  // H2O is read_tau's first species
+        }
+        d.Ttau[at] = stp[q].Ttau[al];
+      }
+      __syncthreads();
+      if (on && al == 0) {
+        double r = rr[0];
+        for (int i = 1; i < NL; ++i) r = (rr[i] > r || rr[i] != rr[i]) ? rr[i] : r;  // NaN-aware max
+        d.resid[c0 + q] = first ? 1e300 : r;
+      }
+      __syncthreads();
+    }
+    // ================= B: column images =================
+    for (int q = 0; q < K; ++q)
+      if (c0 + q < d.ncol)
+        repwvl_pair_image_from(d, c0 + q, lane, img[q], stp[q].T, stp[q].Ttau, stp[q].Tsfc, stp[q].h2o);
+    __syncthreads();
+    // ================= C: radiative transfer =================
+    double acc1[NH + 1], acc2[NH];
+#pragma unroll
+    for (int i = 0; i <= NH; ++i) acc1[i] = 0.0;  // main.cpp:326-327
+#pragma unroll
+    for (int i = 0; i < NH; ++i) acc2[i] = 0.0;
+    for (int w = j; w < d.n_wvl; w += LPC) {
+      // both lanes of a pair share w and col_ok: pair_swap sees both active
+      if (col_ok) repwvl_pair_point<CUBE>(d, img[slot], p, w, lane, st, acc1, acc2);
+    }
+    // ================= D: sum over the column's lane pairs =================
+    // even lane: acc1[i] = E_down[i] (i = 0..10), acc2[k] = E_up[k]; odd lane: acc1[i] = E_up[20-i], acc2[k] = E_down[20-k]
+    __syncthreads();  // the staging columns are free again: scr may be written
+#pragma unroll
+    for (int i = 0; i <= NH; ++i) {
+      double v = acc1[i];
+#pragma unroll
+      for (int off = LPC; off >= 2; off >>= 1) v += __shfl_xor(v, off, 64);
+      if (j == 0 && col_ok) (scr + (size_t)slot * 102 + 2 * NL)[p ? NLEV + NL - i : i] = v;
+    }
+#pragma unroll
+    for (int k = 0; k < NH; ++k) {
+      double v = acc2[k];
+#pragma unroll
+      for (int off = LPC; off >= 2; off >>= 1) v += __shfl_xor(v, off, 64);
+      if (j == 0 && col_ok) (scr + (size_t)slot * 102 + 2 * NL)[p ? NL - k : NLEV + k] = v;
+    }
+    __syncthreads();
+    // ================= E: dE, time step, thermodynamics (main.cpp:337-341, 156-176, 581) =================
+    for (int base = 0; base < K; base += 3) {
+      const int q = base + aq;
+      const bool on = lane < 3 * NL && q < K && c0 + q < d.ncol;
+      const double *E = scr + (size_t)(on ? q : 0) * 102 + 2 * NL;  // E_down[21], E_up[21]
+      double *sdE = scr + (size_t)(on ? q : 0) * 102;                // aliases theta (dead by now)
+      const double *Ed = E, *Eu = E + NLEV;
+      const int c = c0 + q;
+      double dEl = 0.0;
+      if (on) {
+        dEl = Ed[al] - Ed[al + 1] + Eu[al + 1] - Eu[al];                // main.cpp:338
+        if (al == NL - 1) dEl += d.solar_irr[c] + Ed[NL] - Eu[NL];      // main.cpp:341
+        sdE[al] = dEl;
+        d.E_down[(size_t)c * NLEV + al] = Ed[al];
+        d.E_up[(size_t)c * NLEV + al] = Eu[al];
+        if (al == 0) {
+          d.E_down[(size_t)c * NLEV + NL] = Ed[NL];
+          d.E_up[(size_t)c * NLEV + NL] = Eu[NL];
+        }
+      }
+      __syncthreads();
+      if (on) {
+        double mx = sdE[0];
+#pragma unroll
+        for (int i = 1; i < NL; ++i) mx = (mx < sdE[i]) ? sdE[i] : mx;  // signed max_element, main.cpp:157
+        const double heat_cap = 1004.0 * d.dp * 100.0;                  // c_air * dp * 100, main.cpp:157,169
+        double dt = 5.0 / mx * heat_cap / 9.80665;                      // max_dT = 5 (float), main.cpp:82
+        if (dt > 3600 * 12) dt = 3600 * 12;                             // main.cpp:158-160
+        const double Tn = stp[q].T[al] + dEl * dt * 9.80665 / heat_cap; // main.cpp:169
+        stp[q].T[al] = Tn;
+        d.T[(size_t)c * NL + al] = Tn;
+        d.dE[(size_t)c * NL + al] = dEl;
+        if (al == NL - 1) {
+          const double ts = Tn * d.conv[NL - 1];                        // main.cpp:173
+          stp[q].Tsfc = ts;
+          d.Tsfc[c] = ts;
+        }
+        if (al == 0) {
+          d.dt[c] = dt;
+          stp[q].time_h += (float)dt / 3600;                            // main.cpp:581
+          d.time_h[c] = stp[q].time_h;
+        }
+      }
+      __syncthreads();
+    }
+  }
+}
 
 // ---------------------------------------------------------------------------------------------
 // Convective adjustment: theta = T*conv, sort descending, T = theta/conv (main.cpp:123-139,

@@ -20,12 +20,12 @@ import our_first_climate_model_amd as pkg
 LD = np.longdouble
 
 
-def run(n_nodes=4000, log=print):
+def run(n_nodes=4000, log=print, library=None):
     """Returns [(|GPU - exact|, |oracle - exact|, |GPU - oracle|)] per column, W/m^2."""
     out = []
     olib = ol.load()
     inp = H.make_inputs(pkg, "lbl", 2, n_nodes=n_nodes, atm="fpda.lbl.atm")
-    g, o = H.gpu_ensemble(pkg, inp), H.oracle_ensemble(olib, inp)
+    g, o = H.gpu_ensemble(pkg, inp, library=library), H.oracle_ensemble(olib, inp)
     g.step(1), o.step(1)
     fg, fo = g.get_fluxes(), o.get_fluxes()
 

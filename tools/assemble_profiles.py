@@ -17,8 +17,12 @@ import bench  # noqa: E402  (kernel_source_id, the byte constants)
 tag = sys.argv[1]
 wl = sys.argv[2] if len(sys.argv) > 2 else "lbl"
 rnd = sys.argv[3] if len(sys.argv) > 3 else "r02"
-KERNEL = "k_rt_lbl_pair" if wl == "lbl" else "k_rt_repwvl_flat"
 b = json.load(open(f"gpurun_out/bench_{tag}.json"))
+KERNEL = b["roofline"]["kernel"]
+# the PMC runs of a fused kernel cover several steps per launch: counters and times are per LAUNCH there, so they
+# are divided by the steps one launch of the profiled runs covered (profile_session.sh: PM steps / KT steps)
+PM_STEPS = 1 if wl == "lbl" or "k_step" not in KERNEL else 20
+KT_STEPS = 1 if wl == "lbl" or "k_step" not in KERNEL else 200
 ncol = b["config"]["columns_total"]
 nspec = b["config"]["bands"] if wl == "lbl" else b["config"]["wavelengths"]
 points = ncol * nspec
@@ -32,6 +36,9 @@ def agg(d):
         if KERNEL in r["Kernel_Name"]:
             a[r["Counter_Name"]].append(float(r["Counter_Value"]))
             kn = (r["Kernel_Name"], r["VGPR_Count"], r["LDS_Block_Size"], r["Scratch_Size"], r["Grid_Size"])
+    big = {k: max(v) for k, v in a.items()}  # fused kernel: the warm-up launch covers fewer steps; take the timed one
+    if PM_STEPS > 1:
+        return {k: big[k] / PM_STEPS for k in a}, kn
     return {k: sum(v) / len(v) for k, v in a.items()}, kn
 
 
@@ -44,7 +51,7 @@ f4, _ = agg(f"p{tag}f4")
 ks_path = glob.glob(f"gpurun_out/kt{tag}/*/*kernel_stats.csv")[0]
 ks = list(csv.DictReader(open(ks_path)))
 rt = [r for r in ks if KERNEL in r["Name"]][0]
-t = float(rt["AverageNs"]) * 1e-9
+t = float(rt["AverageNs"]) * 1e-9 if KT_STEPS == 1 else float(rt["MaxNs"]) * 1e-9 / KT_STEPS
 clock = g["GRBM_GUI_ACTIVE"] / 8 / t
 if wl == "lbl":
     true_cal = 5 * 20 * (nspec + 1) * 8 + (nspec + 1) * 8

@@ -18,7 +18,7 @@ def build(spec):
     name, _, flags = spec.partition(":")
     flags = [f for f in flags.split(",") if f]
     so = os.path.join(OUT, f"librcm_hip_{name}.so")
-    cmd = ["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "-fPIC", "--offload-arch=gfx950", "-DRCM_EXPERIMENT",
+    cmd = ["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "-fPIC", "--offload-arch=gfx950",
            "-I" + os.path.join(ROOT, "include"), "-I" + os.path.join(PKG, "csrc"), "-shared", "-o", so,
            os.path.join(PKG, "csrc", "rcm_capi.hip"), os.path.join(PKG, "csrc", "rcm_host.cpp"),
            os.path.join(PKG, "csrc", "rcm_nc.cpp"),
