@@ -174,6 +174,9 @@ int choose_lpc(const rcm_ensemble *h) {
     const double cost = (double)((waves + 1023) / 1024) * (double)(passes + 1);
     if (cost < best_cost) best_cost = cost, best = lpc;
   }
+#ifdef RCM_LPC_ENV  // experiments only (tools/build_variants.py): force the lane pairs per column
+  if (const char *v = std::getenv("RCM_LPC")) best = std::atoi(v);
+#endif
   if (h->fusion == 1) return best;
   const int K = 32 / best;
   return ((long)h->ncol + K - 1) / K >= 2048 ? best : 0;

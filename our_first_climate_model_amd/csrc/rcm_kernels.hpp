@@ -42,6 +42,12 @@ constexpr int WPB = 4;       // waves per block = columns per block (one per SIM
 #ifndef RCM_PLK_UNROLL
 #define RCM_PLK_UNROLL 1  // independent band-Planck evaluations in flight
 #endif
+#ifndef RCM_RW_TAU_UNROLL
+#define RCM_RW_TAU_UNROLL 1  // layers of the repwvl optical-depth stage in flight (20 table loads each)
+#endif
+#ifndef RCM_RW_PLK_UNROLL
+#define RCM_RW_PLK_UNROLL 1  // monochromatic Planck evaluations in flight in the repwvl lane-pair kernels
+#endif
 #ifndef RCM_SWEEP_DIFF
 #define RCM_SWEEP_DIFF 1  // recurrences of the lane-pair kernels in difference form (2 FMAs per crossing and angle);
 #endif                    // 0: the emission form L = t*L + (1-t)*B (2.5), kept for A/B runs
@@ -721,7 +727,7 @@ __device__ __forceinline__ void repwvl_pair_tau(const Dev &d, const RepwvlPairLd
   const unsigned ld8 = (unsigned)d.n_wvl * 8u, sp8 = (unsigned)d.n_p * ld8;
   const char *b00 = (const char *)d.xsec, *b01 = b00 + ld8;
   const char *b10 = b00 + (size_t)d.n_species * sp8, *b11 = b10 + ld8;
-#pragma unroll 1
+#pragma unroll RCM_RW_TAU_UNROLL
   for (int k = 0; k < NH; ++k) {
     const unsigned vo = s.xoff[p][k] + (unsigned)w * 8u;
     const double w00 = s.w[p][k][0], w10 = s.w[p][k][1], w01 = s.w[p][k][2], w11 = s.w[p][k][3];
@@ -750,7 +756,7 @@ __device__ __forceinline__ void repwvl_pair_point(const Dev &d, const RepwvlPair
   for (int k = 0; k < NH; ++k) tau[k] = st[k][lane];
   const double xc = d.rw_xc[w];  // h*c/(lambda*kB), main.cpp:70-72,191
   const double sc = d.rw_sc[w];  // weight*2*h*c^2/lambda^5/1e9, main.cpp:190-191
-#pragma unroll 1
+#pragma unroll RCM_RW_PLK_UNROLL
   for (int k = 0; k <= NH; ++k) st[k][lane] = planck_mono_fast(xc, sc, s.T[p][k], s.rT[p][k]);
   double B[NH];
 #pragma unroll

@@ -29,7 +29,8 @@ def build(spec):
     info = []
     lines = r.stderr.splitlines()
     for i, ln in enumerate(lines):
-        if "Function Name: _ZN3rcm13k_rt_lbl_pairILi1" in ln:
+        if any(k in ln for k in ("Function Name: _ZN3rcm13k_rt_lbl_pairILi1", "Function Name: _ZN3rcm16k_rt_repwvl_flatILi1",
+                                 "Function Name: _ZN3rcm13k_step_repwvlILi1ELi16")):
             blk = " ".join(x.split("remark:")[1].split("[-R")[0].strip() for x in lines[i:i + 12]
                            if any(k in x for k in ("Function Name", " VGPRs:", "AGPRs", "ScratchSize", "VGPRs Spill")))
             info.append(blk)

@@ -1,5 +1,7 @@
 #!/usr/bin/env python3
-"""Times the repwvl path (BASELINE.json configs[2]: 10 000 columns, Reduced100) per step, RT kernel and whole step."""
+"""Times the repwvl path (BASELINE.json configs[2]: 10 000 columns, Reduced100) per step for the three launch
+forms: the fused whole-step kernel (k_step_repwvl), the three-kernel path with the flattened RT kernel, and the
+chunked lane-pair kernel.   usage (GPU box): python tools/time_repwvl.py [ncol] [table] [steps]"""
 import os
 import sys
 import time
@@ -13,12 +15,15 @@ import our_first_climate_model_amd as pkg
 
 ncol = int(sys.argv[1]) if len(sys.argv) > 1 else 10000
 table = sys.argv[2] if len(sys.argv) > 2 else "Reduced100"
-steps = 50
+steps = int(sys.argv[3]) if len(sys.argv) > 3 else 200
 inp = H.make_inputs(pkg, "repwvl", ncol, table=table)
-for pair in (0, 1):
-    os.environ["RCM_PAIR"] = str(pair)
+nw = inp["table"]["n_wvl"]
+for name, fusion, chunks in (("fused", 1, 0), ("flat", 0, 0), ("chunked", 0, 1), ("auto", -1, 0)):
     g = H.gpu_ensemble(pkg, inp)
-    g.step(5)
+    g.set_step_fusion(fusion)
+    if chunks:
+        g.set_spectral_chunks(chunks)
+    g.step(20)
     g.sync()
     g.set_rt_timing(True)
     t0 = time.perf_counter()
@@ -26,8 +31,7 @@ for pair in (0, 1):
     g.sync()
     dt = time.perf_counter() - t0
     ms, n = g.get_rt_timing()
-    nw = inp["table"]["n_wvl"]
-    print(f"{table} ncol={ncol} pair={pair}: {dt / steps * 1e3:.3f} ms/step wall, RT kernel {ms / n:.3f} ms, "
-          f"{ncol * steps / dt:.0f} column-timesteps/s, {ncol * nw / (ms / n) / 1e6:.2f} Gpoint/s, "
-          f"chunks={g.get_spectral_chunks()}")
+    print(f"{table} ncol={ncol} {name:8s}: {dt / steps * 1e3:.4f} ms/step wall, kernel {ms / steps:.4f} ms/step ({n} launches), "
+          f"{ncol * steps / dt / 1e6:.2f} M column-timesteps/s, {ncol * nw / (ms / steps) / 1e6:.2f} Gpoint/s, "
+          f"lane pairs/column={g.get_step_fusion()}", flush=True)
     g.close()
