@@ -329,11 +329,48 @@ __global__ __launch_bounds__(64 * WPB, RCM_LB) void k_rt_lbl(Dev d) {
 // Both lanes execute one instruction stream:  L = B[k] + t[k]*(L - B[k]);  acc += w*L.
 // Per lane: 21 accumulators, 10 transmissions, 10 Planck values, 10 optical depths.
 // ---------------------------------------------------------------------------------------------
+// Which lanes form a pair.  RCM_PAIR_LAYOUT 1 (production): rows of 16 lanes alternate in parity -- lanes 0..15 and
+// 32..47 are the "even" halves (layers 0..9) of the spectral points 0..15 and 16..31 of a pass, lanes 16..31 and
+// 48..63 the "odd" halves (layers 19..10) of the same points; partners are 16 lanes apart.  A wave's 8-byte table
+// load then reads 128 contiguous bytes per 16-lane row.  Layout 0 pairs ADJACENT lanes (2i, 2i+1): the hand-over
+// is a DPP quad-permute (two VALU instructions), but a table load alternates between two rows from lane to lane
+// and the texture path handles it at half speed -- measured (tools/ubench/tcp_pattern.hip, L2-resident table, 12
+// waves per CU): 34 cycles per wave-load against 17.5 for rows of 16; the repwvl kernels (200 table loads per
+// point and lane) were bound by exactly that, not by the VALU.  In layout 1 the hand-over is a ds_swizzle
+// (xor 16 within each half of the wave): LDS crossbar, no LDS memory, no VALU instruction.
+#ifndef RCM_PAIR_LAYOUT
+#define RCM_PAIR_LAYOUT 1
+#endif
+#if RCM_PAIR_LAYOUT
+__device__ __forceinline__ int pair_parity(int lane) { return (lane >> 4) & 1; }
+__device__ __forceinline__ int pair_index(int lane) { return (lane & 15) | ((lane >> 5) << 4); }  // 0..31
+__device__ __forceinline__ int pair_lane(int index, int parity) { return (index & 15) | (parity << 4) | ((index >> 4) << 5); }
+// lane offset that flips bit b of the pair index
+__device__ __forceinline__ constexpr int pair_index_bit_offset(int b) { return b < 4 ? (1 << b) : 32; }
+__device__ __forceinline__ double pair_swap(double v) {
+  // ds_swizzle, bit-mask mode: lane' = ((lane & 0x1f) | 0) ^ 0x10 within each group of 32
+  const int lo = __builtin_amdgcn_ds_swizzle(__double2loint(v), 0x401F);
+  const int hi = __builtin_amdgcn_ds_swizzle(__double2hiint(v), 0x401F);
+  return __hiloint2double(hi, lo);
+}
+#else
+__device__ __forceinline__ int pair_parity(int lane) { return lane & 1; }
+__device__ __forceinline__ int pair_index(int lane) { return lane >> 1; }
+__device__ __forceinline__ int pair_lane(int index, int parity) { return 2 * index + parity; }
+__device__ __forceinline__ constexpr int pair_index_bit_offset(int b) { return 2 << b; }
 __device__ __forceinline__ double pair_swap(double v) {
   int lo = __double2loint(v), hi = __double2hiint(v);
   lo = __builtin_amdgcn_update_dpp(lo, lo, 0xB1, 0xF, 0xF, true);  // quad_perm [1,0,3,2]
   hi = __builtin_amdgcn_update_dpp(hi, hi, 0xB1, 0xF, 0xF, true);
   return __hiloint2double(hi, lo);
+}
+#endif
+// Sum of v over the lane pairs whose index differs in the low `bits` bits only (same parity): a butterfly.
+template <int BITS>
+__device__ __forceinline__ double pair_sum(double v) {
+#pragma unroll
+  for (int b = BITS - 1; b >= 0; --b) v += __shfl_xor(v, pair_index_bit_offset(b), 64);
+  return v;
 }
 
 constexpr int NH = NL / 2;  // layers per lane
@@ -479,27 +516,24 @@ __device__ __forceinline__ void pair_all_angles(const Dev &d, const double (&tau
   }
 }
 
-// Reduce the accumulators over the 32 lanes of each parity (offsets 32..2) and store the record.
+// Reduce the accumulators over the 32 lanes of each parity and store the record.
 // even lane: acc1[j] = E_down[j] (j = 0..10), acc2[k] = E_up[k] (k = 0..9)
 // odd lane:  acc1[j] = E_up[20-j],           acc2[k] = E_down[20-k]
 __device__ __forceinline__ void store_pair_partial(const Dev &d, int col, int chunk, int lane, bool valid,
                                                    double (&acc1)[NH + 1], double (&acc2)[NH]) {
   double *oEd = d.partial + ((size_t)col * d.nchunk + chunk) * PSTRIDE, *oEu = oEd + NLEV;
+  const bool w0 = valid && lane == pair_lane(0, 0), w1 = valid && lane == pair_lane(0, 1);
 #pragma unroll
   for (int j = 0; j <= NH; ++j) {
-    double v = acc1[j];
-#pragma unroll
-    for (int off = 32; off >= 2; off >>= 1) v += __shfl_xor(v, off, 64);
-    if (valid && lane == 0) oEd[j] = v;
-    if (valid && lane == 1) oEu[NL - j] = v;
+    const double v = pair_sum<5>(acc1[j]);
+    if (w0) oEd[j] = v;
+    if (w1) oEu[NL - j] = v;
   }
 #pragma unroll
   for (int k = 0; k < NH; ++k) {
-    double v = acc2[k];
-#pragma unroll
-    for (int off = 32; off >= 2; off >>= 1) v += __shfl_xor(v, off, 64);
-    if (valid && lane == 0) oEu[k] = v;
-    if (valid && lane == 1) oEd[NL - k] = v;
+    const double v = pair_sum<5>(acc2[k]);
+    if (w0) oEu[k] = v;
+    if (w1) oEd[NL - k] = v;
   }
 }
 
@@ -583,7 +617,7 @@ __global__ __launch_bounds__(64 * WPB, RCM_PAIR_LB) void k_rt_lbl_pair(Dev d) {
   const long item = valid ? item_raw : nitem - 1;
   const int chunk = (int)(item / d.ncol);
   const int col = (int)(item - (long)chunk * d.ncol);
-  const int p = lane & 1;
+  const int p = pair_parity(lane);
   PairLds &s = s_col[wib];
   double(*st)[64] = s_stage[wib];
 
@@ -610,7 +644,7 @@ __global__ __launch_bounds__(64 * WPB, RCM_PAIR_LB) void k_rt_lbl_pair(Dev d) {
   const long b1 = min(b0 + (long)d.chunk_len, (long)d.nspec);
   const LblAddr ad = lbl_pair_addr(d, p);
 
-  for (long b = b0 + (lane >> 1); b < b1; b += 32) {  // main.cpp:329: 32 bands per wave pass
+  for (long b = b0 + pair_index(lane); b < b1; b += 32) {  // main.cpp:329: 32 bands per wave pass
     // ---- optical depths of the lane's ten layers (lbl composition + cloud, main.cpp:266-274)
     double tau[NH];
     lbl_pair_tau(s, p, ad.sbase, ad.row0 + (unsigned)b * 8u, ad.rstep, st, lane);
@@ -779,7 +813,7 @@ __global__ __launch_bounds__(64 * WPB, RCM_PAIR_LB) void k_rt_repwvl_pair(Dev d)
   const long item = valid ? item_raw : nitem - 1;
   const int chunk = (int)(item / d.ncol);
   const int col = (int)(item - (long)chunk * d.ncol);
-  const int p = lane & 1;
+  const int p = pair_parity(lane);
   RepwvlPairLds &s = s_col[wib];
   double(*st)[64] = s_stage[wib];
   repwvl_pair_image(d, col, lane, s);
@@ -792,7 +826,7 @@ __global__ __launch_bounds__(64 * WPB, RCM_PAIR_LB) void k_rt_repwvl_pair(Dev d)
   for (int j = 0; j < NH; ++j) acc2[j] = 0.0;
   const int w0 = chunk * d.chunk_len;
   const int w1 = min(w0 + d.chunk_len, d.nspec);
-  for (int w = w0 + (lane >> 1); w < w1; w += 32) repwvl_pair_point<CUBE>(d, s, p, w, lane, st, acc1, acc2);
+  for (int w = w0 + pair_index(lane); w < w1; w += 32) repwvl_pair_point<CUBE>(d, s, p, w, lane, st, acc1, acc2);
   store_pair_partial(d, col, chunk, lane, valid, acc1, acc2);
 }
 
@@ -813,7 +847,7 @@ __global__ __launch_bounds__(64 * WPB, RCM_PAIR_LB) void k_rt_repwvl_flat(Dev d,
   const size_t per_wave = (size_t)maxc * sizeof(RepwvlPairLds) + (size_t)(NH + 1) * 64 * sizeof(double);
   RepwvlPairLds *imgs = reinterpret_cast<RepwvlPairLds *>(s_dyn + wib * per_wave);
   double(*st)[64] = reinterpret_cast<double(*)[64]>(s_dyn + wib * per_wave + (size_t)maxc * sizeof(RepwvlPairLds));
-  const int p = lane & 1;
+  const int p = pair_parity(lane);
   const long nw = d.n_wvl;
   const long nflat = (long)d.ncol * nw;
   const long flat0 = ((long)blockIdx.x * WPB + wib) * 32;
@@ -830,7 +864,7 @@ __global__ __launch_bounds__(64 * WPB, RCM_PAIR_LB) void k_rt_repwvl_flat(Dev d,
   for (int j = 0; j <= NH; ++j) acc1[j] = 0.0;
 #pragma unroll
   for (int j = 0; j < NH; ++j) acc2[j] = 0.0;
-  const long flat = flat0 + (lane >> 1);
+  const long flat = flat0 + pair_index(lane);
   if (flat < nflat) {
     const int col = (int)(flat / nw);
     repwvl_pair_point<CUBE>(d, imgs[col - c_first], p, (int)(flat - (long)col * nw), lane, st, acc1, acc2);
@@ -855,7 +889,7 @@ __global__ __launch_bounds__(64 * WPB, RCM_PAIR_LB) void k_rt_repwvl_flat(Dev d,
         const long c = c_first + sl;
         const long seg0 = max(c * nw, flat0), seg1 = min(min((c + 1) * nw, flat0 + 32), nflat);
         double sum = 0.0;
-        for (long f = seg0; f < seg1; ++f) sum += st[idx][2 * (int)(f - flat0) + q];
+        for (long f = seg0; f < seg1; ++f) sum += st[idx][pair_lane((int)(f - flat0), q)];
         const long slot = (seg0 - c * nw + 31) / 32;
         double *oEd = d.partial + ((size_t)c * d.nchunk + slot) * PSTRIDE, *oEu = oEd + NLEV;
         if (round == 0) {
@@ -948,6 +982,7 @@ struct StepLds {     // per owned column
 template <int CUBE, int LPC>
 __global__ __launch_bounds__(64, RCM_PAIR_LB) void k_step_repwvl(Dev d, int first_step, int nsteps) {
   constexpr int K = 32 / LPC;  // columns per wave
+  constexpr int kLog2Lpc = LPC == 32 ? 5 : LPC == 16 ? 4 : LPC == 8 ? 3 : LPC == 4 ? 2 : LPC == 2 ? 1 : 0;
   extern __shared__ __align__(16) unsigned char s_dyn[];
   RepwvlPairLds *img = reinterpret_cast<RepwvlPairLds *>(s_dyn);
   StepLds *stp = reinterpret_cast<StepLds *>(s_dyn + K * sizeof(RepwvlPairLds));
@@ -958,9 +993,9 @@ __global__ __launch_bounds__(64, RCM_PAIR_LB) void k_step_repwvl(Dev d, int firs
   double *scr = (K * 102 <= (NH + 1) * 64) ? &st[0][0] : reinterpret_cast<double *>(st + (NH + 1));
   const int lane = threadIdx.x;
   const int c0 = blockIdx.x * K;
-  const int p = lane & 1;
-  const int slot = (lane >> 1) / LPC;       // which of the wave's columns this lane pair works for
-  const int j = (lane >> 1) - slot * LPC;   // its index among the column's lane pairs
+  const int p = pair_parity(lane);
+  const int slot = pair_index(lane) / LPC;       // which of the wave's columns this lane pair works for
+  const int j = pair_index(lane) - slot * LPC;   // its index among the column's lane pairs
   const bool col_ok = c0 + slot < d.ncol;
   // lanes of phases A / E: (column q, layer l), three columns per round
   const int aq = lane / NL, al = lane - aq * NL;
@@ -1048,16 +1083,12 @@ __global__ __launch_bounds__(64, RCM_PAIR_LB) void k_step_repwvl(Dev d, int firs
     __syncthreads();  // the staging columns are free again: scr may be written
 #pragma unroll
     for (int i = 0; i <= NH; ++i) {
-      double v = acc1[i];
-#pragma unroll
-      for (int off = LPC; off >= 2; off >>= 1) v += __shfl_xor(v, off, 64);
+      const double v = pair_sum<kLog2Lpc>(acc1[i]);
       if (j == 0 && col_ok) (scr + (size_t)slot * 102 + 2 * NL)[p ? NLEV + NL - i : i] = v;
     }
 #pragma unroll
     for (int k = 0; k < NH; ++k) {
-      double v = acc2[k];
-#pragma unroll
-      for (int off = LPC; off >= 2; off >>= 1) v += __shfl_xor(v, off, 64);
+      const double v = pair_sum<kLog2Lpc>(acc2[k]);
       if (j == 0 && col_ok) (scr + (size_t)slot * 102 + 2 * NL)[p ? NL - k : NLEV + k] = v;
     }
     __syncthreads();
@@ -1321,13 +1352,13 @@ __global__ __launch_bounds__(64) void k_tau_pair(Dev d, int col, double *out) {
     RepwvlPairLds rw;
   } img;
   __shared__ double st[NH + 1][64];
-  const int lane = threadIdx.x, p = lane & 1;
+  const int lane = threadIdx.x, p = pair_parity(lane);
   if (d.mode == MODE_REPWVL)
     repwvl_pair_image(d, col, lane, img.rw);
   else
     lbl_pair_image(d, col, lane, img.lbl);
   __syncthreads();
-  const long b = (long)blockIdx.x * 32 + (lane >> 1);
+  const long b = (long)blockIdx.x * 32 + pair_index(lane);
   if (b >= d.nspec) return;
   if (d.mode == MODE_REPWVL) {
     repwvl_pair_tau(d, img.rw, p, (int)b, st, lane);
