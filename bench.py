@@ -168,6 +168,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--backend", default="nccl", choices=("nccl", "gloo"),
                     help="torch.distributed backend; gloo only to rehearse the N>1 path on a one-GPU box")
+    ap.add_argument("--fusion", type=int, default=-1, choices=(-1, 0, 1),
+                    help="repwvl whole-step kernel: -1 automatic (default), 0 never, 1 always (A/B and profiling)")
     ap.add_argument("--dump-state", default=None,
                     help="rank 0 writes the gathered [ncol][21] state to this .npy file (multi-rank parity tests)")
     args = ap.parse_args()
@@ -238,6 +240,8 @@ def main():
     ens = pkg.configure(pkg.Ensemble(ncol_local, device=dev_index, stream=stream), inp)
     if args.chunks:
         ens.set_spectral_chunks(args.chunks)
+    if args.fusion != -1:
+        ens.set_step_fusion(args.fusion)
     packed = torch.empty((ncol_local, 21), dtype=torch.float64, device="cuda")
     log(f"setup {time.perf_counter() - t_setup:.1f} s: {ncol_total} columns ({ncol_local} on this rank), "
         f"{nspec} spectral points, {ens.get_spectral_chunks()} partial records/column")
