@@ -154,7 +154,7 @@ constexpr int kPostSlices = 32;  // blocks per column of the first-stage chunk s
 
 bool use_flat(const rcm_ensemble *h) {
   return h->mode == rcm::MODE_REPWVL && h->flat && h->pair && h->exp_variant == 1 && h->user_chunks == 0 &&
-         h->d.n_wvl >= 8;  // at most 31/8 + 2 = 5 column images per wave
+         h->d.n_wvl >= 8;  // at most 127/8 + 2 = 17 column images per block (45 KB)
 }
 
 // The fused whole-step kernel of the repwvl path (k_step_repwvl): lane pairs per column LPC (a power of two, K =
@@ -213,8 +213,8 @@ void launch_rt_pair(rcm_ensemble *h, int blocks) {
   if (h->mode == rcm::MODE_LBL) {
     hipLaunchKernelGGL((rcm::k_rt_lbl_pair<CUBE>), dim3(blocks), dim3(64 * rcm::WPB), 0, h->stream, h->d);
   } else if (use_flat(h)) {
-    const int maxc = 31 / h->d.n_wvl + 2;
-    const size_t lds = (size_t)rcm::WPB * ((size_t)maxc * sizeof(rcm::RepwvlPairLds) + (size_t)(rcm::NH + 1) * 64 * sizeof(double));
+    const int maxc = (rcm::WPB * 32 - 1) / h->d.n_wvl + 2;  // columns the 128 consecutive items of a block can touch
+    const size_t lds = (size_t)maxc * sizeof(rcm::RepwvlPairLds) + (size_t)rcm::WPB * (rcm::NH + 1) * 64 * sizeof(double);
     const long waves = ((long)h->ncol * h->d.n_wvl + 31) / 32;
     const auto kern = rcm::k_rt_repwvl_flat<CUBE>;
     if (lds > 48 * 1024)
@@ -761,6 +761,19 @@ int rcm_step(rcm_ensemble *h, int nsteps) {
     if (int rc = launch_step(h)) return rc;
   return RCM_OK;
 }
+
+#ifdef RCM_DBG_STAMPS  // profiling builds only; not declared in include/rcm.h
+int rcm_dbg_stamps(rcm_ensemble *h, unsigned long long *out, int n) {
+  if (!h->d.dbg) {
+    HIPCK(hipMalloc((void **)&h->d.dbg, (size_t)n * sizeof(unsigned long long)));
+    HIPCK(hipMemset(h->d.dbg, 0, (size_t)n * sizeof(unsigned long long)));
+    return RCM_OK;
+  }
+  HIPCK(hipStreamSynchronize(h->stream));
+  HIPCK(hipMemcpy(out, h->d.dbg, (size_t)n * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+  return RCM_OK;
+}
+#endif
 
 int rcm_set_step_fusion(rcm_ensemble *h, int mode) {
   if (!h || mode < -1 || mode > 1) return fail(RCM_ERR_ARG, "rcm_set_step_fusion: mode must be -1 (automatic), 0 or 1");

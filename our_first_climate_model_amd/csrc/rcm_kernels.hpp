@@ -65,6 +65,7 @@ struct Dev {
   // (main.cpp:341), grey cloud layer index (-1: none) and optical depth (main.cpp:266-274)
   const double *solar_irr, *cloud_tau;
   const int *cloud_layer;
+  unsigned long long *dbg;  // phase time stamps of sampled waves (builds with -DRCM_DBG_STAMPS only; else null)
   double *resid;  // equilibrium residual per column: max_l |change of the ADJUSTED profile| between the
                   // last two iterations [K] (1e300 until two iterations have run)
   double *Tprev;  // adjusted profile of the previous iteration
@@ -763,7 +764,11 @@ __device__ __forceinline__ void repwvl_pair_tau(const Dev &d, const RepwvlPairLd
   const char *b10 = b00 + (size_t)d.n_species * sp8, *b11 = b10 + ld8;
 #pragma unroll RCM_RW_TAU_UNROLL
   for (int k = 0; k < NH; ++k) {
+#ifdef RCM_DBG_NOLOAD  // ablation builds only (tools/build_variants.py): every lane reads one address
+    const unsigned vo = (s.xoff[p][k] + (unsigned)w * 8u) & 0u;
+#else
     const unsigned vo = s.xoff[p][k] + (unsigned)w * 8u;
+#endif
     const double w00 = s.w[p][k][0], w10 = s.w[p][k][1], w01 = s.w[p][k][2], w11 = s.w[p][k][3];
     double a = 0.0;
 #pragma unroll
@@ -790,14 +795,23 @@ __device__ __forceinline__ void repwvl_pair_point(const Dev &d, const RepwvlPair
   for (int k = 0; k < NH; ++k) tau[k] = st[k][lane];
   const double xc = d.rw_xc[w];  // h*c/(lambda*kB), main.cpp:70-72,191
   const double sc = d.rw_sc[w];  // weight*2*h*c^2/lambda^5/1e9, main.cpp:190-191
+#ifdef RCM_DBG_NOPLANCK  // ablation builds only
+  for (int k = 0; k <= NH; ++k) st[k][lane] = sc * s.rT[p][k] + xc;
+#else
 #pragma unroll RCM_RW_PLK_UNROLL
   for (int k = 0; k <= NH; ++k) st[k][lane] = planck_mono_fast(xc, sc, s.T[p][k], s.rT[p][k]);
+#endif
   double B[NH];
 #pragma unroll
   for (int k = 0; k < NH; ++k) B[k] = st[k][lane];
   const double Linit = p ? st[NH][lane] : 0.0;
 
+#ifdef RCM_DBG_NOANGLES  // ablation builds only
+#pragma unroll
+  for (int k = 0; k < NH; ++k) acc1[k] += tau[k] * B[k] + Linit, acc2[k] += tau[k];
+#else
   pair_all_angles<CUBE>(d, tau, B, Linit, st, lane, acc1, acc2);
+#endif
 }
 
 template <int CUBE>
@@ -832,31 +846,41 @@ __global__ __launch_bounds__(64 * WPB, RCM_PAIR_LB) void k_rt_repwvl_pair(Dev d)
 
 // ---------------------------------------------------------------------------------------------
 // The same, with the (column, wavelength) pairs FLATTENED over the lane pairs: wave i takes the 32
-// consecutive items 32i..32i+31 of the column-major list, whichever columns they belong to (at most
-// 31/n_wvl + 2 of them, each with its own LDS image).  100 wavelengths fill 100/128 of the lane pairs
-// in the chunked kernel, 10 wavelengths 10/32; here every pass is full.  The per-column sums are a
-// segmented reduction through LDS, summed in lane order; a column's partial record goes to slot
-// ceil((first item of the segment - first item of the column)/32), so records never collide and the
-// slots a column never uses stay zero (the buffer is zeroed once).  d.nchunk = number of slots.
+// consecutive items 32i..32i+31 of the column-major list, whichever columns they belong to.  100 wavelengths
+// fill 100/128 of the lane pairs in the chunked kernel, 10 wavelengths 10/32; here every pass is full, and the
+// work comes in 31 250 equal pieces for 10 000 x 100 (whole-column ownership leaves the last third of the run
+// to a partly empty chip, measured with k_step_repwvl).  What a wave does besides its one pass is kept small:
+//  * the column images are shared by the block: its 4 waves cover 128 consecutive items = at most 127/n_wvl + 2
+//    columns, one image each, built by the 4 waves in parallel (before: every wave built its own two);
+//  * the per-column sums are MASKED BUTTERFLIES over the lanes (a lane contributes its sums to the column its
+//    item belongs to and zero to the others), not serial loops through LDS;
+//  * 30.5 KB of LDS per block and <= 128 VGPRs: 4 waves per SIMD.
+// A column's partial record goes to slot ceil((first item of the segment - first item of the column)/32), so
+// records never collide and the slots a column never uses stay zero (the buffer is zeroed once).
+// d.nchunk = number of slots.
 // ---------------------------------------------------------------------------------------------
+#ifndef RCM_FLAT_LB
+#define RCM_FLAT_LB 4  // waves per SIMD k_rt_repwvl_flat is register-allocated for
+#endif
 template <int CUBE>
-__global__ __launch_bounds__(64 * WPB, RCM_PAIR_LB) void k_rt_repwvl_flat(Dev d, int maxc) {
+__global__ __launch_bounds__(64 * WPB, RCM_FLAT_LB) void k_rt_repwvl_flat(Dev d, int maxc) {
   extern __shared__ __align__(16) unsigned char s_dyn[];
   const int lane = threadIdx.x & 63;
   const int wib = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const size_t per_wave = (size_t)maxc * sizeof(RepwvlPairLds) + (size_t)(NH + 1) * 64 * sizeof(double);
-  RepwvlPairLds *imgs = reinterpret_cast<RepwvlPairLds *>(s_dyn + wib * per_wave);
-  double(*st)[64] = reinterpret_cast<double(*)[64]>(s_dyn + wib * per_wave + (size_t)maxc * sizeof(RepwvlPairLds));
+  RepwvlPairLds *imgs = reinterpret_cast<RepwvlPairLds *>(s_dyn);  // the block's columns
+  double(*st)[64] = reinterpret_cast<double(*)[64]>(s_dyn + (size_t)maxc * sizeof(RepwvlPairLds) +
+                                                    (size_t)wib * (NH + 1) * 64 * sizeof(double));
   const int p = pair_parity(lane);
   const long nw = d.n_wvl;
   const long nflat = (long)d.ncol * nw;
-  const long flat0 = ((long)blockIdx.x * WPB + wib) * 32;
-  int c_first = 0, ncw = 0;  // first column and number of columns this wave touches
-  if (flat0 < nflat) {
-    c_first = (int)(flat0 / nw);
-    ncw = (int)(min(flat0 + 31, nflat - 1) / nw) - c_first + 1;
+  const long blk0 = (long)blockIdx.x * (WPB * 32);
+  const long flat0 = blk0 + wib * 32;
+  int cb_first = 0, ncb = 0;  // first column and number of columns the block touches
+  if (blk0 < nflat) {
+    cb_first = (int)(blk0 / nw);
+    ncb = (int)(min(blk0 + WPB * 32 - 1, nflat - 1) / nw) - cb_first + 1;
   }
-  for (int sl = 0; sl < ncw; ++sl) repwvl_pair_image(d, c_first + sl, lane, imgs[sl]);
+  for (int sl = wib; sl < ncb; sl += WPB) repwvl_pair_image(d, cb_first + sl, lane, imgs[sl]);
   __syncthreads();
 
   double acc1[NH + 1], acc2[NH];
@@ -865,41 +889,34 @@ __global__ __launch_bounds__(64 * WPB, RCM_PAIR_LB) void k_rt_repwvl_flat(Dev d,
 #pragma unroll
   for (int j = 0; j < NH; ++j) acc2[j] = 0.0;
   const long flat = flat0 + pair_index(lane);
+  int col = -1;
   if (flat < nflat) {
-    const int col = (int)(flat / nw);
-    repwvl_pair_point<CUBE>(d, imgs[col - c_first], p, (int)(flat - (long)col * nw), lane, st, acc1, acc2);
+    col = (int)(flat / nw);
+    repwvl_pair_point<CUBE>(d, imgs[col - cb_first], p, (int)(flat - (long)col * nw), lane, st, acc1, acc2);
   }
+  if (flat0 >= nflat) return;  // (whole wave)
 
-  // ---- segmented reduction: round 0 = acc1 (11 values per parity), round 1 = acc2 (10 values)
+  // ---- segmented reduction: one masked butterfly per column of the wave's 32 items (fixed order)
+  // even lane: acc1[j] = E_down[j] (j = 0..10), acc2[k] = E_up[k] (k = 0..9)
+  // odd lane:  acc1[j] = E_up[20-j],           acc2[k] = E_down[20-k]
+  const int c_first = (int)(flat0 / nw), c_last = (int)(min(flat0 + 31, nflat - 1) / nw);
+  const bool w0 = lane == pair_lane(0, 0), w1 = lane == pair_lane(0, 1);
+  for (int c = c_first; c <= c_last; ++c) {
+    const bool mine = col == c;
+    const long seg0 = max((long)c * nw, flat0);
+    const long slot = (seg0 - (long)c * nw + 31) / 32;
+    double *oEd = d.partial + ((size_t)c * d.nchunk + slot) * PSTRIDE, *oEu = oEd + NLEV;
 #pragma unroll
-  for (int round = 0; round < 2; ++round) {
-    const int nv = round == 0 ? NH + 1 : NH;
-    __syncthreads();  // the staging column is free (previous readers are done)
-    if (round == 0) {
-#pragma unroll
-      for (int j = 0; j <= NH; ++j) st[j][lane] = acc1[j];
-    } else {
-#pragma unroll
-      for (int j = 0; j < NH; ++j) st[j][lane] = acc2[j];
+    for (int j = 0; j <= NH; ++j) {
+      const double v = pair_sum<5>(mine ? acc1[j] : 0.0);
+      if (w0) oEd[j] = v;
+      if (w1) oEu[NL - j] = v;
     }
-    __syncthreads();
-    if (lane < 2 * nv) {
-      const int q = lane / nv, idx = lane - q * nv;
-      for (int sl = 0; sl < ncw; ++sl) {
-        const long c = c_first + sl;
-        const long seg0 = max(c * nw, flat0), seg1 = min(min((c + 1) * nw, flat0 + 32), nflat);
-        double sum = 0.0;
-        for (long f = seg0; f < seg1; ++f) sum += st[idx][pair_lane((int)(f - flat0), q)];
-        const long slot = (seg0 - c * nw + 31) / 32;
-        double *oEd = d.partial + ((size_t)c * d.nchunk + slot) * PSTRIDE, *oEu = oEd + NLEV;
-        if (round == 0) {
-          if (q == 0) oEd[idx] = sum;       // E_down[idx], idx = 0..10
-          else oEu[NL - idx] = sum;         // E_up[20-idx]
-        } else {
-          if (q == 0) oEu[idx] = sum;       // E_up[idx], idx = 0..9
-          else oEd[NL - idx] = sum;         // E_down[20-idx]
-        }
-      }
+#pragma unroll
+    for (int k = 0; k < NH; ++k) {
+      const double v = pair_sum<5>(mine ? acc2[k] : 0.0);
+      if (w0) oEu[k] = v;
+      if (w1) oEd[NL - k] = v;
     }
   }
 }
@@ -979,6 +996,18 @@ struct StepLds {     // per owned column
   float time_h;      // the column's clock (a float, main.cpp:359)
 };
 
+#ifdef RCM_DBG_STAMPS  // profiling builds only: lane 0 of every 61st wave writes s_memtime at phase boundaries of its last step
+#define RCM_STAMP(i)                                                                                        \
+  do {                                                                                                      \
+    if (d.dbg && step == nsteps - 1 && threadIdx.x == 0 && blockIdx.x % 61 == 0)                            \
+      d.dbg[(size_t)(blockIdx.x / 61) * 64 + (i)] = __builtin_amdgcn_s_memtime();                           \
+  } while (0)
+#else
+#define RCM_STAMP(i) \
+  do {               \
+  } while (0)
+#endif
+
 template <int CUBE, int LPC>
 __global__ __launch_bounds__(64, RCM_PAIR_LB) void k_step_repwvl(Dev d, int first_step, int nsteps) {
   constexpr int K = 32 / LPC;  // columns per wave
@@ -1016,6 +1045,7 @@ __global__ __launch_bounds__(64, RCM_PAIR_LB) void k_step_repwvl(Dev d, int firs
 
   for (int step = 0; step < nsteps; ++step) {
     const bool first = first_step && step == 0;
+    RCM_STAMP(0);
     // ================= A: adjustment, residual, feedback (main.cpp:536-572) =================
     for (int base = 0; base < K; base += 3) {
       const int q = base + aq;
@@ -1063,11 +1093,13 @@ __global__ __launch_bounds__(64, RCM_PAIR_LB) void k_step_repwvl(Dev d, int firs
       }
       __syncthreads();
     }
+    RCM_STAMP(1);
     // ================= B: column images =================
     for (int q = 0; q < K; ++q)
       if (c0 + q < d.ncol)
         repwvl_pair_image_from(d, c0 + q, lane, img[q], stp[q].T, stp[q].Ttau, stp[q].Tsfc, stp[q].h2o);
     __syncthreads();
+    RCM_STAMP(2);
     // ================= C: radiative transfer =================
     double acc1[NH + 1], acc2[NH];
 #pragma unroll
@@ -1077,7 +1109,9 @@ __global__ __launch_bounds__(64, RCM_PAIR_LB) void k_step_repwvl(Dev d, int firs
     for (int w = j; w < d.n_wvl; w += LPC) {
       // both lanes of a pair share w and col_ok: pair_swap sees both active
       if (col_ok) repwvl_pair_point<CUBE>(d, img[slot], p, w, lane, st, acc1, acc2);
+      RCM_STAMP(8 + (w - j) / LPC);
     }
+    RCM_STAMP(3);
     // ================= D: sum over the column's lane pairs =================
     // even lane: acc1[i] = E_down[i] (i = 0..10), acc2[k] = E_up[k]; odd lane: acc1[i] = E_up[20-i], acc2[k] = E_down[20-k]
     __syncthreads();  // the staging columns are free again: scr may be written
@@ -1092,6 +1126,7 @@ __global__ __launch_bounds__(64, RCM_PAIR_LB) void k_step_repwvl(Dev d, int firs
       if (j == 0 && col_ok) (scr + (size_t)slot * 102 + 2 * NL)[p ? NL - k : NLEV + k] = v;
     }
     __syncthreads();
+    RCM_STAMP(4);
     // ================= E: dE, time step, thermodynamics (main.cpp:337-341, 156-176, 581) =================
     for (int base = 0; base < K; base += 3) {
       const int q = base + aq;
@@ -1137,6 +1172,7 @@ __global__ __launch_bounds__(64, RCM_PAIR_LB) void k_step_repwvl(Dev d, int firs
       }
       __syncthreads();
     }
+    RCM_STAMP(5);
   }
 }
 

@@ -1,0 +1,46 @@
+#!/usr/bin/env python3
+"""Phase durations inside the fused repwvl kernel from s_memtime stamps of sampled waves (a library built with
+-DRCM_DBG_STAMPS: python tools/build_variants.py stamps:-DRCM_DBG_STAMPS).  usage (GPU box): phase_stamps.py [ncol]"""
+import ctypes as C
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import numpy as np
+import torch  # noqa: F401
+import helpers as H
+import our_first_climate_model_amd as pkg
+
+ncol = int(sys.argv[1]) if len(sys.argv) > 1 else 10000
+L = pkg.load_library(os.path.join(ROOT, "our_first_climate_model_amd", "variants", "librcm_hip_stamps.so"))
+L.rcm_dbg_stamps.argtypes = [C.c_void_p, C.POINTER(C.c_ulonglong), C.c_int]
+inp = H.make_inputs(pkg, "repwvl", ncol, table="Reduced100")
+g = H.gpu_ensemble(pkg, inp, library=L)
+g.set_step_fusion(1)
+lpc = g.get_step_fusion()
+nwaves = (ncol + 32 // lpc - 1) // (32 // lpc)
+nsamp = (nwaves + 60) // 61
+buf = np.zeros(nsamp * 64, dtype=np.uint64)
+g.step(5)
+assert L.rcm_dbg_stamps(g.h, buf.ctypes.data_as(C.POINTER(C.c_ulonglong)), buf.size) == 0  # allocates
+g.step(20)
+assert L.rcm_dbg_stamps(g.h, buf.ctypes.data_as(C.POINTER(C.c_ulonglong)), buf.size) == 0
+s = buf.reshape(nsamp, 64).astype(np.float64)
+ok = s[:, 5] > 0
+s = s[ok]
+tick = 1e6 / 100e6  # s_memtime counts at 100 MHz: us per tick
+names = [("A adjust+feedback", 0, 1), ("B images", 1, 2), ("C RT, all passes", 2, 3), ("D reduce", 3, 4), ("E time step", 4, 5),
+         ("whole step", 0, 5)]
+print(f"{ncol} columns, {lpc} lane pairs per column, {len(s)} sampled waves; durations in us (median / p10 / p90)")
+for n, a, b in names:
+    d = (s[:, b] - s[:, a]) * tick
+    print(f"  {n:22s} {np.median(d):8.2f} {np.percentile(d, 10):8.2f} {np.percentile(d, 90):8.2f}")
+npass = (100 + lpc - 1) // lpc
+prev = s[:, 2]
+for i in range(npass):
+    cur = s[:, 8 + i]
+    d = (cur - prev) * tick
+    print(f"  pass {i}                 {np.median(d):8.2f} {np.percentile(d, 10):8.2f} {np.percentile(d, 90):8.2f}")
+    prev = cur

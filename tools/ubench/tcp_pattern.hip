@@ -26,7 +26,7 @@ __global__ __launch_bounds__(256) void k(const double *tab, long ld, int nrows, 
   for (int it = 0; it < iters; ++it) {
     double v[20];
 #pragma unroll
-    for (int j = 0; j < 20; ++j) v[j] = tab[(size_t)(r0 + 2 * j + row * 1) * ld + (size_t)(row ? 17 : 0) * ld + col + (it & 3) * 32];
+    for (int j = 0; j < 20; ++j) v[j] = tab[(size_t)(r0 + 2 * j + row * 1) * ld + (size_t)(row ? 17 : 0) * ld + col + (it & 1) * 32];
 #pragma unroll
     for (int j = 0; j < 20; ++j) acc += v[j];
     r0 = (r0 + 41) % (unsigned)(nrows - 40 - 17);
@@ -48,25 +48,38 @@ float run(const double *tab, long ld, int nrows, int iters, double *out, int blo
   return ms;
 }
 
+int bench(long ld, int shift);
+
 int main() {
-  const long ld = 128;     // doubles per row: 1 KiB rows (Reduced100 rows are 800 B)
-  const int nrows = 3321;  // 9*9*41 rows: 3.4 MB table, L2-resident like xsec of Reduced100
+  bench(128, 0);  // 1 KiB rows, 128-B aligned row segments
+  bench(100, 0);  // Reduced100 as it is: 800-B rows, segments start at any multiple of 32 B
+  bench(112, 0);  // rows padded to a multiple of 128 B
+  bench(128, 3);  // aligned rows, but the wave's columns start 24 B into a line (a flattened item list)
+  return 0;
+}
+
+int bench(long ld, int shift) {
+  const int nrows = 3321;  // 9*9*41 rows: ~3 MB table, L2-resident like xsec of Reduced100
   std::vector<double> h((size_t)nrows * ld, 1.0);
   double *tab, *out;
   hipMalloc(&tab, h.size() * 8), hipMalloc(&out, 8);
   hipMemcpy(tab, h.data(), h.size() * 8, hipMemcpyHostToDevice);
+  const double *tabs = tab + shift;
+  printf("---- row length %ld doubles, column shift %d doubles\n", ld, shift);
   const int iters = 200, blocks = 256 * 3;  // 12 waves per CU
   const char *names[5] = {"contiguous", "pair-interleave [ABAB]", "quad [AABB]", "row16", "half-wave"};
   float ms[5];
-  ms[0] = run<0>(tab, ld, nrows, iters, out, blocks);
-  ms[1] = run<1>(tab, ld, nrows, iters, out, blocks);
-  ms[2] = run<2>(tab, ld, nrows, iters, out, blocks);
-  ms[3] = run<3>(tab, ld, nrows, iters, out, blocks);
-  ms[4] = run<4>(tab, ld, nrows, iters, out, blocks);
+  ms[0] = run<0>(tabs, ld, nrows, iters, out, blocks);
+  ms[1] = run<1>(tabs, ld, nrows, iters, out, blocks);
+  ms[2] = run<2>(tabs, ld, nrows, iters, out, blocks);
+  ms[3] = run<3>(tabs, ld, nrows, iters, out, blocks);
+  ms[4] = run<4>(tabs, ld, nrows, iters, out, blocks);
   for (int p = 0; p < 5; ++p) {
     const double loads_per_cu = 12.0 * iters * 20;  // wave-level load instructions per CU
     printf("%-24s %8.3f ms  %6.1f ns per wave-load per CU (%5.1f cycles at 2.4 GHz)\n", names[p], ms[p],
            ms[p] * 1e6 / loads_per_cu, ms[p] * 1e6 / loads_per_cu * 2.4);
   }
+  hipFree(tab), hipFree(out);
+  (void)hipFree(tab), (void)hipFree(out);
   return 0;
 }
