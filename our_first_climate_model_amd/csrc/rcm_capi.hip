@@ -53,6 +53,8 @@ struct rcm_ensemble {
   int gather_rows = 0;
   // repwvl host copies needed to (re)derive per-layer constants
   std::vector<double> p_grid;
+  std::vector<double> xsec_t;  // xsec re-laid out [t][s][p][w] (host copy: the per-layer table is re-derived with the grid)
+  double *d_xp = nullptr;      // [layer][t][s][w]: xsec interpolated to the layer's mid pressure (derive_repwvl_layers)
   int *d_ip = nullptr;
   double *d_delP = nullptr, *d_numDens = nullptr;
   // timing
@@ -110,6 +112,27 @@ int derive_repwvl_layers(rcm_ensemble *h) {
     ip[o] = lp;
     delP[o] = (midP - h->p_grid[lp]) / (h->p_grid[lp + 1] - h->p_grid[lp]);  // :240
     numDens[o] = (p_dn - p_up) * avog / molMassAir / earthAccel;              // :202
+  }
+  // The pressure half of read_tau's bilinear interpolation (:235-241) does not depend on the column: every
+  // column shares the pressure grid, so the layer's bracket ip and delP are per-handle constants.  The table is
+  // therefore interpolated to each layer's mid pressure ONCE, here:
+  //   xp[l][t][s][w] = x[t][s][ip_l][w] + delP_l * (x[t][s][ip_l+1][w] - x[t][s][ip_l][w])
+  // (20 layers x 9 x 9 x n_wvl doubles: 1.3 MB for Reduced100, less than the table itself) and the kernels
+  // interpolate in temperature only: 2 table loads and 2 FMAs per species and layer instead of 4 and 5.
+  // c0 + cT*dT + cP*dP + cPT*dT*dP of the reference is (1-dT)*xp[it] + dT*xp[it+1] up to rounding
+  // (rcm_get_tau keeps the reference's form; rcm_get_tau_production returns this one).
+  {
+    const Dev &d = h->d;
+    const size_t nw = (size_t)d.n_wvl, rows = (size_t)d.n_tpert * d.n_species;
+    std::vector<double> xp((size_t)NL * rows * nw);
+    for (int l = 0; l < NL; ++l)
+      for (size_t r = 0; r < rows; ++r) {
+        const double *x0 = &h->xsec_t[(r * d.n_p + ip[l]) * nw], *x1 = x0 + nw;
+        double *o = &xp[((size_t)l * rows + r) * nw];
+        for (size_t w = 0; w < nw; ++w) o[w] = std::fma(delP[l], x1[w] - x0[w], x0[w]);
+      }
+    HIPCK(hipMemcpyAsync(h->d_xp, xp.data(), xp.size() * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    HIPCK(hipStreamSynchronize(h->stream));  // xp goes out of scope
   }
   HIPCK(hipMemcpyAsync(h->d_ip, ip.data(), NL * sizeof(int), hipMemcpyHostToDevice, h->stream));
   HIPCK(hipMemcpyAsync(h->d_delP, delP.data(), NL * sizeof(double), hipMemcpyHostToDevice, h->stream));
@@ -638,6 +661,8 @@ int rcm_set_repwvl_tables(rcm_ensemble *h, int n_tpert, int n_species, int n_wvl
   }
   int rc = 0;
   rc = rc ? rc : dev_upload(h, (double **)&d.xsec, xt.data(), xt.size());
+  rc = rc ? rc : dev_alloc(h, &h->d_xp, (size_t)NL * n_tpert * n_species * n_wvl);
+  d.xp = h->d_xp;
   rc = rc ? rc : dev_upload(h, (double **)&d.t_ref, t_ref, (size_t)n_p);
   rc = rc ? rc : dev_upload(h, (double **)&d.t_pert, t_pert, (size_t)n_tpert);
   rc = rc ? rc : dev_upload(h, (double **)&d.pnum, pnum.data(), (size_t)n_wvl);
@@ -647,6 +672,7 @@ int rcm_set_repwvl_tables(rcm_ensemble *h, int n_tpert, int n_species, int n_wvl
   rc = rc ? rc : dev_upload(h, (double **)&d.rw_sc, rw_sc.data(), (size_t)n_wvl);
   if (rc) return rc;
   h->p_grid.assign(p_grid, p_grid + n_p);
+  h->xsec_t = std::move(xt);
   d.n_tpert = n_tpert, d.n_species = n_species, d.n_p = n_p, d.n_wvl = n_wvl;
   d.nspec = n_wvl;
   d.ngas = RCM_NSPEC_REPWVL;
@@ -767,6 +793,7 @@ int rcm_dbg_stamps(rcm_ensemble *h, unsigned long long *out, int n) {
   if (!h->d.dbg) {
     HIPCK(hipMalloc((void **)&h->d.dbg, (size_t)n * sizeof(unsigned long long)));
     HIPCK(hipMemset(h->d.dbg, 0, (size_t)n * sizeof(unsigned long long)));
+    HIPCK(hipMemcpyToSymbol(HIP_SYMBOL(rcm::g_stamps), &h->d.dbg, sizeof(h->d.dbg)));
     return RCM_OK;
   }
   HIPCK(hipStreamSynchronize(h->stream));

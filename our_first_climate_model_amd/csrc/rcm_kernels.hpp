@@ -54,6 +54,18 @@ constexpr int WPB = 4;       // waves per block = columns per block (one per SIM
 
 enum { MODE_NONE = -1, MODE_REPWVL = 0, MODE_LBL = 1 };
 
+#ifdef RCM_DBG_STAMPS  // profiling builds only (tools/phase_stamps.py): s_memtime at phase boundaries of sampled waves
+__device__ unsigned long long *g_stamps = nullptr;  // set by rcm_dbg_stamps
+__device__ __forceinline__ void stamp(bool sampled, int sample, int i) {
+  if (sampled && g_stamps) g_stamps[(size_t)sample * 64 + i] = __builtin_amdgcn_s_memtime();
+}
+#define RCM_PT_STAMP(i) stamp((threadIdx.x & 63) == 0 && (blockIdx.x % 61) == 0 && (threadIdx.x >> 6) == 0, blockIdx.x / 61, (i))
+#else
+#define RCM_PT_STAMP(i) \
+  do {                 \
+  } while (0)
+#endif
+
 // Everything a kernel needs, passed by value.
 struct Dev {
   int ncol, nangle, mode, ngas;
@@ -80,6 +92,7 @@ struct Dev {
   long lbl_ld;
   // repwvl: xsec[t][s][p][w] (wavelength fastest)
   const double *xsec, *t_ref, *t_pert, *delP, *numDens, *pnum, *lam5, *lkb;
+  const double *xp;  // [layer][t][s][w]: xsec interpolated to the layer's mid pressure (host, with the grid)
   const double *rw_xc, *rw_sc;  // per wavelength: h*c/(lambda*kB) and pnum/lam5/1e9 (planck_mono_fast), host-formed
   const int *ip;
   int n_tpert, n_species, n_p, n_wvl;
@@ -698,14 +711,15 @@ __global__ __launch_bounds__(64 * WPB, RCM_PAIR_LB) void k_rt_lbl_pair(Dev d) {
 struct RepwvlPairLds {
   double T[2][NH + 1];   // T[p][k] = Tlayer[layer(p,k)], k = NH: T_surface
   double rT[2][NH + 1];  // 1/T
-  // numDens (:246) times the four bilinear weights of the layer's (T, p) bracket: corners (it, ip),
-  // (it+1, ip), (it, ip+1), (it+1, ip+1).  The reference forms c0 + cT*delT + cP*delP + cPT*delT*delP from
-  // corner DIFFERENCES (:235-241); the weighted sum of the corners is the same number up to rounding
-  // (rcm_get_tau, k_tau, keeps the reference's form) for 5 instead of 11 instructions per species and layer.
-  double w[2][NH][4];
-  double vmr[2][RCM_NSPEC_REPWVL][NH];
+  // Per layer and species the two coefficients of the temperature interpolation on the pressure-interpolated
+  // table xp (derive_repwvl_layers): cA = numDens*(1-delT)*vmr, cB = numDens*delT*vmr, so that
+  //   tau = sum_s cA_s * xp[l][it][s][w] + cB_s * xp[l][it+1][s][w]
+  // is read_tau's numDens * sum_s vmr_s * (c0 + cT*delT + cP*delP + cPT*delT*delP) (:235-246) up to rounding
+  // (rcm_get_tau, k_tau, keeps the reference's corner-difference form): 2 loads and 2 FMAs per species and layer.
+  double cA[2][RCM_NSPEC_REPWVL][NH], cB[2][RCM_NSPEC_REPWVL][NH];
+  double wA[2][NH], wB[2][NH];  // numDens*(1-delT), numDens*delT (scratch of the image build)
   double cloud[2][NH];   // grey cloud optical depth of the layer (main.cpp:266-274), 0 elsewhere
-  unsigned xoff[2][NH];  // byte offset of xsec[it][0][ip][0]: the (T, p) bracket of the layer (:229-232)
+  unsigned xoff[2][NH];  // byte offset of xp[l][it][0][0]: the layer's temperature bracket (:229-232)
 };
 
 // Fills the LDS image of column `col`: per (parity, position) the temperature bracket of read_tau
@@ -730,19 +744,21 @@ __device__ __forceinline__ void repwvl_pair_image_from(const Dev &d, int col, in
       const double *tp = d.t_pert;
       const int it = lower_pos_dev([&](int j) { return tr + tp[j]; }, d.n_tpert, midT);  // :229-232
       const double t0 = tr + tp[it], t1 = tr + tp[it + 1];
-      s.xoff[q][k] = (unsigned)(((size_t)it * d.n_species * d.n_p + ip) * d.n_wvl * sizeof(double));
+      s.xoff[q][k] = (unsigned)((((size_t)layer * d.n_tpert + it) * d.n_species) * d.n_wvl * sizeof(double));
       const double dT = (midT - t0) / (t1 - t0);  // :239
-      const double dP = d.delP[layer], nd = d.numDens[layer];
-      const double w11 = dT * dP, w10 = dT - w11, w01 = dP - w11, w00 = (1.0 - dT) - w01;
-      s.w[q][k][0] = nd * w00, s.w[q][k][1] = nd * w10, s.w[q][k][2] = nd * w01, s.w[q][k][3] = nd * w11;
+      const double nd = d.numDens[layer];
+      s.wA[q][k] = nd * (1.0 - dT), s.wB[q][k] = nd * dT;
       s.cloud[q][k] = (layer == d.cloud_layer[col]) ? d.cloud_tau[col] : 0.0;
     }
   }
+  __builtin_amdgcn_wave_barrier();  // one wave builds an image: its LDS operations execute in program order
   for (int i = lane; i < 2 * RCM_NSPEC_REPWVL * NH; i += 64) {
     const int q = i / (RCM_NSPEC_REPWVL * NH), r = i - q * (RCM_NSPEC_REPWVL * NH);
     const int sp = r / NH, k = r - sp * NH;
     const int layer = q ? NL - 1 - k : k;
-    s.vmr[q][sp][k] = sp == 0 ? h2o[layer] : d.gas[((size_t)col * RCM_NSPEC_REPWVL + sp) * NL + layer];
+    const double vmr = sp == 0 ? h2o[layer] : d.gas[((size_t)col * RCM_NSPEC_REPWVL + sp) * NL + layer];
+    s.cA[q][sp][k] = s.wA[q][k] * vmr;  // :244 and :246 folded into the interpolation weights
+    s.cB[q][sp][k] = s.wB[q][k] * vmr;
   }
 }
 
@@ -756,12 +772,11 @@ __device__ __forceinline__ void repwvl_pair_image(const Dev &d, int col, int lan
 // kernels; k_tau_pair dumps it.  s = the lane's column image.
 __device__ __forceinline__ void repwvl_pair_tau(const Dev &d, const RepwvlPairLds &s, int p, int w, double (*st)[64],
                                                 int lane) {
-  // xsec[t][s][p][w]: the four corners of a bracket sit at fixed distances (next pressure: n_wvl, next
-  // temperature: n_species*n_p*n_wvl), so four scalar bases + one 32-bit byte offset per (layer, species)
-  // address them (the table is < 4 GiB, rcm_set_repwvl_tables checks)
-  const unsigned ld8 = (unsigned)d.n_wvl * 8u, sp8 = (unsigned)d.n_p * ld8;
-  const char *b00 = (const char *)d.xsec, *b01 = b00 + ld8;
-  const char *b10 = b00 + (size_t)d.n_species * sp8, *b11 = b10 + ld8;
+  // xp[l][t][s][w]: the two temperature corners of a layer's bracket are n_species*n_wvl doubles apart, the
+  // species n_wvl: two scalar bases + one 32-bit byte offset per (layer, species) address them (the table is
+  // < 4 GiB, rcm_set_repwvl_tables checks)
+  const unsigned ld8 = (unsigned)d.n_wvl * 8u;
+  const char *bA = (const char *)d.xp, *bB = bA + (size_t)d.n_species * ld8;
 #pragma unroll RCM_RW_TAU_UNROLL
   for (int k = 0; k < NH; ++k) {
 #ifdef RCM_DBG_NOLOAD  // ablation builds only (tools/build_variants.py): every lane reads one address
@@ -769,16 +784,12 @@ __device__ __forceinline__ void repwvl_pair_tau(const Dev &d, const RepwvlPairLd
 #else
     const unsigned vo = s.xoff[p][k] + (unsigned)w * 8u;
 #endif
-    const double w00 = s.w[p][k][0], w10 = s.w[p][k][1], w01 = s.w[p][k][2], w11 = s.w[p][k][3];
     double a = 0.0;
 #pragma unroll
     for (int sp = 0; sp < RCM_NSPEC_REPWVL; ++sp) {
       if (!((d.species_mask >> sp) & 1u)) continue;  // vmr == 0 everywhere: the term is +0
-      const unsigned v = vo + (unsigned)sp * sp8;
-      const double xs = fma(w11, *(const double *)(b11 + v),
-                            fma(w01, *(const double *)(b01 + v),
-                                fma(w10, *(const double *)(b10 + v), w00 * *(const double *)(b00 + v))));
-      a = fma(xs, s.vmr[p][sp][k], a);  // :244, with numDens (:246) already in the weights
+      const unsigned v = vo + (unsigned)sp * ld8;
+      a = fma(s.cA[p][sp][k], *(const double *)(bA + v), fma(s.cB[p][sp][k], *(const double *)(bB + v), a));
     }
     st[k][lane] = clamp_tau(a + s.cloud[p][k]);  // main.cpp:266-274; + 0.0 leaves the other layers as they are
   }
@@ -790,9 +801,11 @@ template <int CUBE>
 __device__ __forceinline__ void repwvl_pair_point(const Dev &d, const RepwvlPairLds &s, int p, int w, int lane,
                                                   double (*st)[64], double (&acc1)[NH + 1], double (&acc2)[NH]) {
   double tau[NH];
+  RCM_PT_STAMP(20);
   repwvl_pair_tau(d, s, p, w, st, lane);
 #pragma unroll
   for (int k = 0; k < NH; ++k) tau[k] = st[k][lane];
+  RCM_PT_STAMP(21);
   const double xc = d.rw_xc[w];  // h*c/(lambda*kB), main.cpp:70-72,191
   const double sc = d.rw_sc[w];  // weight*2*h*c^2/lambda^5/1e9, main.cpp:190-191
 #ifdef RCM_DBG_NOPLANCK  // ablation builds only
@@ -805,6 +818,7 @@ __device__ __forceinline__ void repwvl_pair_point(const Dev &d, const RepwvlPair
 #pragma unroll
   for (int k = 0; k < NH; ++k) B[k] = st[k][lane];
   const double Linit = p ? st[NH][lane] : 0.0;
+  RCM_PT_STAMP(22);
 
 #ifdef RCM_DBG_NOANGLES  // ablation builds only
 #pragma unroll
@@ -812,6 +826,7 @@ __device__ __forceinline__ void repwvl_pair_point(const Dev &d, const RepwvlPair
 #else
   pair_all_angles<CUBE>(d, tau, B, Linit, st, lane, acc1, acc2);
 #endif
+  RCM_PT_STAMP(23);
 }
 
 template <int CUBE>
@@ -880,8 +895,10 @@ __global__ __launch_bounds__(64 * WPB, RCM_FLAT_LB) void k_rt_repwvl_flat(Dev d,
     cb_first = (int)(blk0 / nw);
     ncb = (int)(min(blk0 + WPB * 32 - 1, nflat - 1) / nw) - cb_first + 1;
   }
+  RCM_PT_STAMP(16);
   for (int sl = wib; sl < ncb; sl += WPB) repwvl_pair_image(d, cb_first + sl, lane, imgs[sl]);
   __syncthreads();
+  RCM_PT_STAMP(17);
 
   double acc1[NH + 1], acc2[NH];
 #pragma unroll
@@ -919,6 +936,7 @@ __global__ __launch_bounds__(64 * WPB, RCM_FLAT_LB) void k_rt_repwvl_flat(Dev d,
       if (w1) oEd[NL - k] = v;
     }
   }
+  RCM_PT_STAMP(18);
 }
 
 #ifdef RCM_WITH_VARIANTS
