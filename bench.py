@@ -168,8 +168,6 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--backend", default="nccl", choices=("nccl", "gloo"),
                     help="torch.distributed backend; gloo only to rehearse the N>1 path on a one-GPU box")
-    ap.add_argument("--fusion", type=int, default=-1, choices=(-1, 0, 1),
-                    help="repwvl whole-step kernel: -1 automatic (default), 0 never, 1 always (A/B and profiling)")
     ap.add_argument("--dump-state", default=None,
                     help="rank 0 writes the gathered [ncol][21] state to this .npy file (multi-rank parity tests)")
     args = ap.parse_args()
@@ -240,8 +238,6 @@ def main():
     ens = pkg.configure(pkg.Ensemble(ncol_local, device=dev_index, stream=stream), inp)
     if args.chunks:
         ens.set_spectral_chunks(args.chunks)
-    if args.fusion != -1:
-        ens.set_step_fusion(args.fusion)
     packed = torch.empty((ncol_local, 21), dtype=torch.float64, device="cuda")
     log(f"setup {time.perf_counter() - t_setup:.1f} s: {ncol_total} columns ({ncol_local} on this rank), "
         f"{nspec} spectral points, {ens.get_spectral_chunks()} partial records/column")
@@ -283,15 +279,12 @@ def main():
         np.save(args.dump_state, final.cpu().numpy())
 
     if rank == 0:
-        # per STEP: the lbl path launches its RT kernel once per step; the fused repwvl kernel (k_step_repwvl) covers
-        # all K steps in rt_n launches, so the HIP-event time is divided by the steps it covers
-        rt_avg_s = rt_ms / 1e3 / args.steps
+        rt_avg_s = rt_ms / 1e3 / max(rt_n, 1)
         per_point = BYTES_PER_BAND if lbl else BYTES_PER_RWVL
-        alg_bytes = per_point * nspec * ncol_local  # per step on this rank
+        alg_bytes = per_point * nspec * ncol_local  # per RT launch on this rank
         achieved = alg_bytes / rt_avg_s / 1e9
         tag = "r02_lbl" if lbl else "r02_repwvl100"
-        fused = (not lbl) and ens.get_step_fusion() > 0
-        kern = "k_rt_lbl_pair" if lbl else ("k_step_repwvl" if fused else "k_rt_repwvl_flat")
+        kern = "k_rt_lbl_pair" if lbl else "k_rt_repwvl_flat"
         valu, pmc = valu_issue(tag, kern, nspec * ncol_local, rt_avg_s)
         # HBM bytes per launch from the PMC passes committed under profiles/ (2 x FETCH_SIZE + WRITE_SIZE, the
         # gfx950 correction of MI355X_MICROARCH.md's HBM section); only valid for the workload they were collected on
@@ -319,9 +312,7 @@ def main():
                       "perturbations": "CO2 x linspace(0.5,4)"}
             note = ("numerator = 26 584 B per (column, wavelength): the xsec table slice + (lambda, weight), as if "
                     "every column read the table itself (SURVEY 8d); the 2.66 MB table lives in L2, the kernel is "
-                    "fp64-VALU-issue bound (profiles/README.md); avg_launch_ms and algorithmic_bytes_per_launch are "
-                    "per STEP: the fused kernel k_step_repwvl runs steps_per_launch iterations per launch and its "
-                    "time includes adjustment, feedback and time step (there is no separate kernel for them)")
+                    "limited by the lock-step of texture-path and VALU phases of its one-pass waves (profiles/README.md)")
         config["parallelism"] = f"columns sharded over {world} GPU(s), one all-gather at the end"
         out = {
             "metric": "column_timesteps_per_sec", "value": ncol_total * args.steps / elapsed,
@@ -331,8 +322,7 @@ def main():
             "roofline": {"bound": "hbm", "actual_bound": "fp64_valu_issue", "kernel": kern, "achieved": achieved,
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "traffic_source": traffic_src, "algorithmic_bytes_per_launch": alg_bytes,
-                         "avg_launch_ms": rt_avg_s * 1e3, "launches": rt_n, "steps_per_launch": args.steps / max(rt_n, 1),
-                         "fp64_valu_issue": valu, "note": note},
+                         "avg_launch_ms": rt_avg_s * 1e3, "launches": rt_n, "fp64_valu_issue": valu, "note": note},
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(pkg, inp, args.workload, log)

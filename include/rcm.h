@@ -179,15 +179,6 @@ int rcm_gather(rcm_ensemble *h, void *nccl_comm, void *dev_recv, int ncol_pad);
 int rcm_set_spectral_chunks(rcm_ensemble *h, int nchunk);
 int rcm_get_spectral_chunks(rcm_ensemble *h);
 
-/* repwvl path, big ensembles: the whole loop body (adjustment, feedback, optical depths, radiative transfer,
- * time step) runs as ONE kernel in which every wave owns a few columns and iterates on them without leaving
- * the kernel (rcm_step(h, n) is then a single launch for up to 512 iterations).  mode -1 (default): the library
- * decides by ensemble size (>= 2 waves per SIMD); 0: never (three kernels per iteration); 1: always.  Results do
- * not depend on the choice beyond the order of the spectral sum (<= 1e-10 W/m^2).  rcm_get_step_fusion returns
- * the lane pairs per column in use (2..32), or 0 when the three-kernel path would run.  No effect on lbl. */
-int rcm_set_step_fusion(rcm_ensemble *h, int mode);
-int rcm_get_step_fusion(rcm_ensemble *h);
-
 /* Kernel timing with HIP events on the handle's stream, around every thermal-RT launch (the fused repwvl
  * kernel counts as ONE launch however many iterations it covers).
  * rcm_get_rt_timing synchronises, returns the accumulated milliseconds and launch count since

@@ -180,6 +180,7 @@ bool use_flat(const rcm_ensemble *h) {
          h->d.n_wvl >= 8;  // at most 127/8 + 2 = 17 column images per block (45 KB)
 }
 
+#ifdef RCM_WITH_VARIANTS
 // The fused whole-step kernel of the repwvl path (k_step_repwvl): lane pairs per column LPC (a power of two, K =
 // 32/LPC columns per wave).  Cost model in wave passes per SIMD: a wave runs ceil(n_wvl/LPC) passes (+ ~1 for the
 // phases around them), ceil(ncol/K) waves share 1024 SIMDs.  10 000 x 100: LPC 16 (5 000 waves x 7 passes = 35
@@ -201,9 +202,10 @@ int choose_lpc(const rcm_ensemble *h) {
   if (const char *v = std::getenv("RCM_LPC")) best = std::atoi(v);
 #endif
   if (h->fusion == 1) return best;
-  const int K = 32 / best;
-  return ((long)h->ncol + K - 1) / K >= 2048 ? best : 0;
+  return 0;  // automatic = the three-kernel path: the fused kernel is slower at every size measured
 }
+
+#endif  // RCM_WITH_VARIANTS
 
 int ensure_partials(rcm_ensemble *h) {
   if (use_flat(h)) {
@@ -288,6 +290,23 @@ void launch_rt(rcm_ensemble *h, int blocks) {
   launch_rt_pair<1>(h, blocks);
 }
 
+int timing_begin(rcm_ensemble *h, hipEvent_t *e1) {
+  *e1 = nullptr;
+  if (!h->timing) return RCM_OK;
+  if (h->events_used == h->events.size()) {
+    hipEvent_t a, b;
+    HIPCK(hipEventCreate(&a));
+    HIPCK(hipEventCreate(&b));
+    h->events.emplace_back(a, b);
+  }
+  const hipEvent_t e0 = h->events[h->events_used].first;
+  *e1 = h->events[h->events_used].second;
+  ++h->events_used;
+  HIPCK(hipEventRecord(e0, h->stream));
+  return RCM_OK;
+}
+
+#ifdef RCM_WITH_VARIANTS
 template <int CUBE, int LPC>
 void launch_fused_lpc(rcm_ensemble *h, int first, int nsteps) {
   constexpr int K = 32 / LPC;
@@ -308,22 +327,6 @@ void launch_fused(rcm_ensemble *h, int lpc, int first, int nsteps) {
     case 4: launch_fused_lpc<CUBE, 4>(h, first, nsteps); break;
     default: launch_fused_lpc<CUBE, 2>(h, first, nsteps); break;
   }
-}
-
-int timing_begin(rcm_ensemble *h, hipEvent_t *e1) {
-  *e1 = nullptr;
-  if (!h->timing) return RCM_OK;
-  if (h->events_used == h->events.size()) {
-    hipEvent_t a, b;
-    HIPCK(hipEventCreate(&a));
-    HIPCK(hipEventCreate(&b));
-    h->events.emplace_back(a, b);
-  }
-  const hipEvent_t e0 = h->events[h->events_used].first;
-  *e1 = h->events[h->events_used].second;
-  ++h->events_used;
-  HIPCK(hipEventRecord(e0, h->stream));
-  return RCM_OK;
 }
 
 // `nsteps` iterations of the repwvl path in ONE launch (k_step_repwvl); long runs are cut into launches of at most
@@ -347,6 +350,8 @@ int launch_fused_steps(rcm_ensemble *h, int lpc, int nsteps) {
   }
   return RCM_OK;
 }
+
+#endif  // RCM_WITH_VARIANTS
 
 int launch_step(rcm_ensemble *h) {
   Dev &d = h->d;
@@ -780,7 +785,9 @@ int rcm_step(rcm_ensemble *h, int nsteps) {
   if (h->mode == rcm::MODE_NONE || !h->have_grid || !h->have_columns)
     return fail(RCM_ERR_STATE, "rcm_step: grid, spectral tables and columns must be set first");
   if (int rc = use_device(h)) return rc;
+#ifdef RCM_WITH_VARIANTS
   if (const int lpc = choose_lpc(h)) return launch_fused_steps(h, lpc, nsteps);
+#endif
   if (!h->d.partial)
     if (int rc = ensure_partials(h)) return rc;
   for (int i = 0; i < nsteps; ++i)
@@ -802,6 +809,7 @@ int rcm_dbg_stamps(rcm_ensemble *h, unsigned long long *out, int n) {
 }
 #endif
 
+#ifdef RCM_WITH_VARIANTS  // test-side build only; not declared in include/rcm.h
 int rcm_set_step_fusion(rcm_ensemble *h, int mode) {
   if (!h || mode < -1 || mode > 1) return fail(RCM_ERR_ARG, "rcm_set_step_fusion: mode must be -1 (automatic), 0 or 1");
   h->fusion = mode;
@@ -812,6 +820,7 @@ int rcm_get_step_fusion(rcm_ensemble *h) {
   if (!h || h->mode == rcm::MODE_NONE) return fail(RCM_ERR_STATE, "rcm_get_step_fusion: tables not set");
   return choose_lpc(h);
 }
+#endif
 
 int rcm_sync(rcm_ensemble *h) {
   if (!h) return fail(RCM_ERR_ARG, "rcm_sync: NULL handle");

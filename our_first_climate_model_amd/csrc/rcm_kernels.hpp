@@ -343,49 +343,92 @@ __global__ __launch_bounds__(64 * WPB, RCM_LB) void k_rt_lbl(Dev d) {
 // Both lanes execute one instruction stream:  L = B[k] + t[k]*(L - B[k]);  acc += w*L.
 // Per lane: 21 accumulators, 10 transmissions, 10 Planck values, 10 optical depths.
 // ---------------------------------------------------------------------------------------------
-// Which lanes form a pair.  RCM_PAIR_LAYOUT 1 (production): rows of 16 lanes alternate in parity -- lanes 0..15 and
-// 32..47 are the "even" halves (layers 0..9) of the spectral points 0..15 and 16..31 of a pass, lanes 16..31 and
-// 48..63 the "odd" halves (layers 19..10) of the same points; partners are 16 lanes apart.  A wave's 8-byte table
-// load then reads 128 contiguous bytes per 16-lane row.  Layout 0 pairs ADJACENT lanes (2i, 2i+1): the hand-over
-// is a DPP quad-permute (two VALU instructions), but a table load alternates between two rows from lane to lane
-// and the texture path handles it at half speed -- measured (tools/ubench/tcp_pattern.hip, L2-resident table, 12
-// waves per CU): 34 cycles per wave-load against 17.5 for rows of 16; the repwvl kernels (200 table loads per
-// point and lane) were bound by exactly that, not by the VALU.  In layout 1 the hand-over is a ds_swizzle
-// (xor 16 within each half of the wave): LDS crossbar, no LDS memory, no VALU instruction.
-#ifndef RCM_PAIR_LAYOUT
-#define RCM_PAIR_LAYOUT 1
+// Which lanes form a pair: a policy of the lane-pair kernels.
+// Pair<0> pairs ADJACENT lanes (2i, 2i+1): the hand-over of the radiance at level 10 is a DPP quad-permute (two VALU
+//   instructions, no latency to speak of), but a wave's 8-byte table load alternates between two table rows from
+//   lane to lane, which the texture path handles at about half speed (tools/ubench/tcp_pattern.hip, L2-resident
+//   table, 12 waves per CU: 34 cycles per wave-load against 17.5 when 16 consecutive lanes read one row).
+// Pair<1> alternates ROWS OF 16 LANES: lanes 0..15 and 32..47 are the "even" halves (layers 0..9) of the spectral
+//   points 0..15 and 16..31 of a pass, lanes 16..31 and 48..63 the "odd" halves (layers 19..10) of the same points;
+//   partners are 16 lanes apart and the hand-over is a ds_swizzle (LDS crossbar, no LDS memory, no VALU
+//   instruction, but ~100 cycles of latency inside the dependent chain of an angle).
+// Measured on one box (tools/ab_libs.py): lbl kernel, 50 loads per pass: Pair<0> 71.1 ms, Pair<1> 72.4 ms per
+// 2048-column launch; flattened repwvl kernel, 100 loads per pass: Pair<0> 407 us, Pair<1> 380 us per step.  So
+// the lbl kernel pairs adjacent lanes and the repwvl kernels rows of 16 (RCM_LBL_LAYOUT / RCM_RW_LAYOUT).
+#ifndef RCM_LBL_LAYOUT
+#define RCM_LBL_LAYOUT 0
 #endif
-#if RCM_PAIR_LAYOUT
-__device__ __forceinline__ int pair_parity(int lane) { return (lane >> 4) & 1; }
-__device__ __forceinline__ int pair_index(int lane) { return (lane & 15) | ((lane >> 5) << 4); }  // 0..31
-__device__ __forceinline__ int pair_lane(int index, int parity) { return (index & 15) | (parity << 4) | ((index >> 4) << 5); }
-// lane offset that flips bit b of the pair index
-__device__ __forceinline__ constexpr int pair_index_bit_offset(int b) { return b < 4 ? (1 << b) : 32; }
-__device__ __forceinline__ double pair_swap(double v) {
-  // ds_swizzle, bit-mask mode: lane' = ((lane & 0x1f) | 0) ^ 0x10 within each group of 32
-  const int lo = __builtin_amdgcn_ds_swizzle(__double2loint(v), 0x401F);
-  const int hi = __builtin_amdgcn_ds_swizzle(__double2hiint(v), 0x401F);
-  return __hiloint2double(hi, lo);
-}
-#else
-__device__ __forceinline__ int pair_parity(int lane) { return lane & 1; }
-__device__ __forceinline__ int pair_index(int lane) { return lane >> 1; }
-__device__ __forceinline__ int pair_lane(int index, int parity) { return 2 * index + parity; }
-__device__ __forceinline__ constexpr int pair_index_bit_offset(int b) { return 2 << b; }
-__device__ __forceinline__ double pair_swap(double v) {
+#ifndef RCM_RW_LAYOUT
+#define RCM_RW_LAYOUT 1
+#endif
+
+// v of the lane OFF lanes away (xor): DPP inside a row of 16 lanes, ds_swizzle / ds_bpermute across rows.
+template <int OFF>
+__device__ __forceinline__ double lane_xor(double v) {
   int lo = __double2loint(v), hi = __double2hiint(v);
-  lo = __builtin_amdgcn_update_dpp(lo, lo, 0xB1, 0xF, 0xF, true);  // quad_perm [1,0,3,2]
-  hi = __builtin_amdgcn_update_dpp(hi, hi, 0xB1, 0xF, 0xF, true);
+  if constexpr (OFF == 1) {  // quad_perm [1,0,3,2]
+    lo = __builtin_amdgcn_update_dpp(lo, lo, 0xB1, 0xF, 0xF, true);
+    hi = __builtin_amdgcn_update_dpp(hi, hi, 0xB1, 0xF, 0xF, true);
+  } else if constexpr (OFF == 2) {  // quad_perm [2,3,0,1]
+    lo = __builtin_amdgcn_update_dpp(lo, lo, 0x4E, 0xF, 0xF, true);
+    hi = __builtin_amdgcn_update_dpp(hi, hi, 0x4E, 0xF, 0xF, true);
+  } else if constexpr (OFF == 16) {  // ds_swizzle, bit-mask mode: lane' = lane ^ 0x10 within each group of 32
+    lo = __builtin_amdgcn_ds_swizzle(lo, 0x401F);
+    hi = __builtin_amdgcn_ds_swizzle(hi, 0x401F);
+  } else {
+    return __shfl_xor(v, OFF, 64);
+  }
   return __hiloint2double(hi, lo);
 }
-#endif
-// Sum of v over the lane pairs whose index differs in the low `bits` bits only (same parity): a butterfly.
-template <int BITS>
-__device__ __forceinline__ double pair_sum(double v) {
+
+template <int LAYOUT>
+struct Pair;
+
+template <>
+struct Pair<0> {  // adjacent lanes
+  static __device__ __forceinline__ int parity(int lane) { return lane & 1; }
+  static __device__ __forceinline__ int index(int lane) { return lane >> 1; }  // 0..31
+  static __device__ __forceinline__ int lane_of(int index, int parity) { return 2 * index + parity; }
+  static __device__ __forceinline__ double swap(double v) { return lane_xor<1>(v); }
+  // Sum of v over the lane pairs whose index differs in the low BITS bits only (same parity): a butterfly.
+  template <int BITS>
+  static __device__ __forceinline__ double sum(double v) {
 #pragma unroll
-  for (int b = BITS - 1; b >= 0; --b) v += __shfl_xor(v, pair_index_bit_offset(b), 64);
-  return v;
-}
+    for (int b = BITS - 1; b >= 0; --b) v += __shfl_xor(v, 2 << b, 64);
+    return v;
+  }
+};
+
+template <>
+struct Pair<1> {  // rows of 16 lanes
+  static __device__ __forceinline__ int parity(int lane) { return (lane >> 4) & 1; }
+  static __device__ __forceinline__ int index(int lane) { return (lane & 15) | ((lane >> 5) << 4); }
+  static __device__ __forceinline__ int lane_of(int index, int parity) { return (index & 15) | (parity << 4) | ((index >> 4) << 5); }
+  static __device__ __forceinline__ double swap(double v) { return lane_xor<16>(v); }
+  // Within a row of 16 lanes the levels 4 and 8 are row rotations (only the lanes that store read the result:
+  // the order of the sum is fixed).
+  template <int BITS>
+  static __device__ __forceinline__ double sum(double v) {
+    if constexpr (BITS >= 1) v += lane_xor<1>(v);
+    if constexpr (BITS >= 2) v += lane_xor<2>(v);
+    if constexpr (BITS == 3) v += __shfl_xor(v, 4, 64);  // half a row: a rotation would reach into the other half
+    if constexpr (BITS >= 4) {  // row_ror:4 -- after the quad levels every lane holds its quad's sum
+      int lo = __double2loint(v), hi = __double2hiint(v);
+      lo = __builtin_amdgcn_update_dpp(lo, lo, 0x124, 0xF, 0xF, true);
+      hi = __builtin_amdgcn_update_dpp(hi, hi, 0x124, 0xF, 0xF, true);
+      v += __hiloint2double(hi, lo);
+      lo = __double2loint(v), hi = __double2hiint(v);  // row_ror:8
+      lo = __builtin_amdgcn_update_dpp(lo, lo, 0x128, 0xF, 0xF, true);
+      hi = __builtin_amdgcn_update_dpp(hi, hi, 0x128, 0xF, 0xF, true);
+      v += __hiloint2double(hi, lo);
+    }
+    if constexpr (BITS >= 5) v += __shfl_xor(v, 32, 64);
+    return v;
+  }
+};
+
+using PairLbl = Pair<RCM_LBL_LAYOUT>;
+using PairRw = Pair<RCM_RW_LAYOUT>;
 
 constexpr int NH = NL / 2;  // layers per lane
 
@@ -405,11 +448,12 @@ struct PairSrc {
   // saturated VALU, two VGPRs are not.
 };
 
+template <class P>
 __device__ __forceinline__ void pair_source(const double (&B)[NH], double Linit, double wsum, PairSrc &src,
                                             double (*st)[64], int lane, double (&acc1)[NH + 1], double (&acc2)[NH]) {
   acc1[0] = fma(wsum, Linit, acc1[0]);  // the surface term of main.cpp:302, all angles at once
 #if RCM_SWEEP_DIFF
-  const double Bp = pair_swap(B[NH - 1]);
+  const double Bp = P::swap(B[NH - 1]);
 #pragma unroll
   for (int k = 0; k < NH - 1; ++k) src.dB[k] = B[k] - B[k + 1];
   src.dB[NH - 1] = B[NH - 1] - Bp;
@@ -433,7 +477,7 @@ __device__ __forceinline__ void pair_source(const double (&B)[NH], double Linit,
 // One angle (odd angle number m) on the lane pair, then -- while m is divisible by 3 -- the angle m/3
 // with the cubed transmissions (t_{m/3} = t_m^3).  Nested straight-line code (DEPTH levels; 3^4 = 81
 // covers nangle <= 64) instead of a loop: a loop makes the compiler carry t[] through register copies.
-template <int DEPTH>
+template <class P, int DEPTH>
 __device__ __forceinline__ void pair_chain(const Dev &d, const double (&t)[NH], const PairSrc &src,
                                            const double *x0, int m, double (&acc1)[NH + 1], double (&acc2)[NH]) {
   const double cw = d.ang[d.nangle + ((m - 1) >> 1)];
@@ -444,7 +488,7 @@ __device__ __forceinline__ void pair_chain(const Dev &d, const double (&t)[NH], 
     X = fma(t[k], X, src.dB[k]);
     acc1[k + 1] = fma(cw, X, acc1[k + 1]);
   }
-  X = pair_swap(X);  // level 10: the down radiance moves to the odd lane, the up radiance to the even lane
+  X = P::swap(X);  // level 10: the down radiance moves to the odd lane, the up radiance to the even lane
 #pragma unroll
   for (int k = NH - 1; k >= 1; --k) {
     X = fma(t[k], X, -src.dB[k - 1]);
@@ -463,7 +507,7 @@ __device__ __forceinline__ void pair_chain(const Dev &d, const double (&t)[NH], 
     X = fma(t[k], X, e[k]);
     acc1[k + 1] = fma(cw, X, acc1[k + 1]);
   }
-  X = pair_swap(X);
+  X = P::swap(X);
 #pragma unroll
   for (int k = NH - 1; k >= 0; --k) {
     X = fma(t[k], X, e[k]);
@@ -475,7 +519,7 @@ __device__ __forceinline__ void pair_chain(const Dev &d, const double (&t)[NH], 
       double t3[NH];
 #pragma unroll
       for (int k = 0; k < NH; ++k) t3[k] = t[k] * t[k] * t[k];
-      pair_chain<DEPTH - 1>(d, t3, src, x0, m / 3, acc1, acc2);
+      pair_chain<P, DEPTH - 1>(d, t3, src, x0, m / 3, acc1, acc2);
     }
   }
 }
@@ -489,20 +533,20 @@ __device__ __forceinline__ void pair_chain(const Dev &d, const double (&t)[NH], 
 // a1 = -log2(e)/mu of the exponential to evaluate and code = 4*n + mode, mode 0: plain root n, 1: a1 is the
 // generator of (n = 3m, 5m), u^3 is parked in the lane's LDS column st (free during the angle loop),
 // 2: n = 5m, transmissions come back from st.
-template <int CUBE>
+template <class P, int CUBE>
 __device__ __forceinline__ void pair_all_angles(const Dev &d, const double (&tau)[NH], const double (&B)[NH],
                                                 double Linit, double (*st)[64], int lane, double (&acc1)[NH + 1],
                                                 double (&acc2)[NH]) {
   const int na = d.nangle;
   PairSrc src;
-  pair_source(B, Linit, d.ang[2 * na], src, st, lane, acc1, acc2);
+  pair_source<P>(B, Linit, d.ang[2 * na], src, st, lane, acc1, acc2);
   if constexpr (!CUBE) {
     for (int n = 2 * na - 1; n >= 1; n -= 2) {
       const double a1 = -d.ang[(n - 1) >> 1] * 0x1.71547652b82fep+0;
       double t[NH];
 #pragma unroll
       for (int k = 0; k < NH; ++k) t[k] = exp_trans(tau[k], a1);  // main.cpp:209
-      pair_chain<0>(d, t, src, &st[NH][lane], n, acc1, acc2);
+      pair_chain<P, 0>(d, t, src, &st[NH][lane], n, acc1, acc2);
     }
   } else {
     const double *sched = d.ang + 2 * na + 1;
@@ -525,7 +569,7 @@ __device__ __forceinline__ void pair_all_angles(const Dev &d, const double (&tau
           }
         }
       }
-      pair_chain<4>(d, t, src, &st[NH][lane], code >> 2, acc1, acc2);
+      pair_chain<P, 4>(d, t, src, &st[NH][lane], code >> 2, acc1, acc2);
     }
   }
 }
@@ -533,19 +577,20 @@ __device__ __forceinline__ void pair_all_angles(const Dev &d, const double (&tau
 // Reduce the accumulators over the 32 lanes of each parity and store the record.
 // even lane: acc1[j] = E_down[j] (j = 0..10), acc2[k] = E_up[k] (k = 0..9)
 // odd lane:  acc1[j] = E_up[20-j],           acc2[k] = E_down[20-k]
+template <class P>
 __device__ __forceinline__ void store_pair_partial(const Dev &d, int col, int chunk, int lane, bool valid,
                                                    double (&acc1)[NH + 1], double (&acc2)[NH]) {
   double *oEd = d.partial + ((size_t)col * d.nchunk + chunk) * PSTRIDE, *oEu = oEd + NLEV;
-  const bool w0 = valid && lane == pair_lane(0, 0), w1 = valid && lane == pair_lane(0, 1);
+  const bool w0 = valid && lane == P::lane_of(0, 0), w1 = valid && lane == P::lane_of(0, 1);
 #pragma unroll
   for (int j = 0; j <= NH; ++j) {
-    const double v = pair_sum<5>(acc1[j]);
+    const double v = P::template sum<5>(acc1[j]);
     if (w0) oEd[j] = v;
     if (w1) oEu[NL - j] = v;
   }
 #pragma unroll
   for (int k = 0; k < NH; ++k) {
-    const double v = pair_sum<5>(acc2[k]);
+    const double v = P::template sum<5>(acc2[k]);
     if (w0) oEu[k] = v;
     if (w1) oEd[NL - k] = v;
   }
@@ -631,7 +676,7 @@ __global__ __launch_bounds__(64 * WPB, RCM_PAIR_LB) void k_rt_lbl_pair(Dev d) {
   const long item = valid ? item_raw : nitem - 1;
   const int chunk = (int)(item / d.ncol);
   const int col = (int)(item - (long)chunk * d.ncol);
-  const int p = pair_parity(lane);
+  const int p = PairLbl::parity(lane);
   PairLds &s = s_col[wib];
   double(*st)[64] = s_stage[wib];
 
@@ -658,7 +703,7 @@ __global__ __launch_bounds__(64 * WPB, RCM_PAIR_LB) void k_rt_lbl_pair(Dev d) {
   const long b1 = min(b0 + (long)d.chunk_len, (long)d.nspec);
   const LblAddr ad = lbl_pair_addr(d, p);
 
-  for (long b = b0 + pair_index(lane); b < b1; b += 32) {  // main.cpp:329: 32 bands per wave pass
+  for (long b = b0 + PairLbl::index(lane); b < b1; b += 32) {  // main.cpp:329: 32 bands per wave pass
     // ---- optical depths of the lane's ten layers (lbl composition + cloud, main.cpp:266-274)
     double tau[NH];
     lbl_pair_tau(s, p, ad.sbase, ad.row0 + (unsigned)b * 8u, ad.rstep, st, lane);
@@ -696,10 +741,10 @@ __global__ __launch_bounds__(64 * WPB, RCM_PAIR_LB) void k_rt_lbl_pair(Dev d) {
 #pragma unroll
     for (int k = 0; k < NH; ++k) B[k] = st[k][lane];
     const double Linit = p ? st[NH][lane] : 0.0;  // main.cpp:300-301
-    pair_all_angles<CUBE>(d, tau, B, Linit, st, lane, acc1, acc2);
+    pair_all_angles<PairLbl, CUBE>(d, tau, B, Linit, st, lane, acc1, acc2);
   }
 
-  store_pair_partial(d, col, chunk, lane, valid, acc1, acc2);
+  store_pair_partial<PairLbl>(d, col, chunk, lane, valid, acc1, acc2);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -824,7 +869,7 @@ __device__ __forceinline__ void repwvl_pair_point(const Dev &d, const RepwvlPair
 #pragma unroll
   for (int k = 0; k < NH; ++k) acc1[k] += tau[k] * B[k] + Linit, acc2[k] += tau[k];
 #else
-  pair_all_angles<CUBE>(d, tau, B, Linit, st, lane, acc1, acc2);
+  pair_all_angles<PairRw, CUBE>(d, tau, B, Linit, st, lane, acc1, acc2);
 #endif
   RCM_PT_STAMP(23);
 }
@@ -842,7 +887,7 @@ __global__ __launch_bounds__(64 * WPB, RCM_PAIR_LB) void k_rt_repwvl_pair(Dev d)
   const long item = valid ? item_raw : nitem - 1;
   const int chunk = (int)(item / d.ncol);
   const int col = (int)(item - (long)chunk * d.ncol);
-  const int p = pair_parity(lane);
+  const int p = PairRw::parity(lane);
   RepwvlPairLds &s = s_col[wib];
   double(*st)[64] = s_stage[wib];
   repwvl_pair_image(d, col, lane, s);
@@ -855,8 +900,8 @@ __global__ __launch_bounds__(64 * WPB, RCM_PAIR_LB) void k_rt_repwvl_pair(Dev d)
   for (int j = 0; j < NH; ++j) acc2[j] = 0.0;
   const int w0 = chunk * d.chunk_len;
   const int w1 = min(w0 + d.chunk_len, d.nspec);
-  for (int w = w0 + pair_index(lane); w < w1; w += 32) repwvl_pair_point<CUBE>(d, s, p, w, lane, st, acc1, acc2);
-  store_pair_partial(d, col, chunk, lane, valid, acc1, acc2);
+  for (int w = w0 + PairRw::index(lane); w < w1; w += 32) repwvl_pair_point<CUBE>(d, s, p, w, lane, st, acc1, acc2);
+  store_pair_partial<PairRw>(d, col, chunk, lane, valid, acc1, acc2);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -885,7 +930,7 @@ __global__ __launch_bounds__(64 * WPB, RCM_FLAT_LB) void k_rt_repwvl_flat(Dev d,
   RepwvlPairLds *imgs = reinterpret_cast<RepwvlPairLds *>(s_dyn);  // the block's columns
   double(*st)[64] = reinterpret_cast<double(*)[64]>(s_dyn + (size_t)maxc * sizeof(RepwvlPairLds) +
                                                     (size_t)wib * (NH + 1) * 64 * sizeof(double));
-  const int p = pair_parity(lane);
+  const int p = PairRw::parity(lane);
   const long nw = d.n_wvl;
   const long nflat = (long)d.ncol * nw;
   const long blk0 = (long)blockIdx.x * (WPB * 32);
@@ -905,7 +950,7 @@ __global__ __launch_bounds__(64 * WPB, RCM_FLAT_LB) void k_rt_repwvl_flat(Dev d,
   for (int j = 0; j <= NH; ++j) acc1[j] = 0.0;
 #pragma unroll
   for (int j = 0; j < NH; ++j) acc2[j] = 0.0;
-  const long flat = flat0 + pair_index(lane);
+  const long flat = flat0 + PairRw::index(lane);
   int col = -1;
   if (flat < nflat) {
     col = (int)(flat / nw);
@@ -917,7 +962,7 @@ __global__ __launch_bounds__(64 * WPB, RCM_FLAT_LB) void k_rt_repwvl_flat(Dev d,
   // even lane: acc1[j] = E_down[j] (j = 0..10), acc2[k] = E_up[k] (k = 0..9)
   // odd lane:  acc1[j] = E_up[20-j],           acc2[k] = E_down[20-k]
   const int c_first = (int)(flat0 / nw), c_last = (int)(min(flat0 + 31, nflat - 1) / nw);
-  const bool w0 = lane == pair_lane(0, 0), w1 = lane == pair_lane(0, 1);
+  const bool w0 = lane == PairRw::lane_of(0, 0), w1 = lane == PairRw::lane_of(0, 1);
   for (int c = c_first; c <= c_last; ++c) {
     const bool mine = col == c;
     const long seg0 = max((long)c * nw, flat0);
@@ -925,13 +970,13 @@ __global__ __launch_bounds__(64 * WPB, RCM_FLAT_LB) void k_rt_repwvl_flat(Dev d,
     double *oEd = d.partial + ((size_t)c * d.nchunk + slot) * PSTRIDE, *oEu = oEd + NLEV;
 #pragma unroll
     for (int j = 0; j <= NH; ++j) {
-      const double v = pair_sum<5>(mine ? acc1[j] : 0.0);
+      const double v = PairRw::sum<5>(mine ? acc1[j] : 0.0);
       if (w0) oEd[j] = v;
       if (w1) oEu[NL - j] = v;
     }
 #pragma unroll
     for (int k = 0; k < NH; ++k) {
-      const double v = pair_sum<5>(mine ? acc2[k] : 0.0);
+      const double v = PairRw::sum<5>(mine ? acc2[k] : 0.0);
       if (w0) oEu[k] = v;
       if (w1) oEd[NL - k] = v;
     }
@@ -986,8 +1031,15 @@ __global__ __launch_bounds__(64 * WPB, 2) void k_rt_repwvl(Dev d) {
 
 #endif  // RCM_WITH_VARIANTS
 
+#ifdef RCM_WITH_VARIANTS
 // ---------------------------------------------------------------------------------------------
-// THE WHOLE TIME-LOOP BODY main.cpp:531-583 FOR THE repwvl PATH IN ONE KERNEL (big ensembles).
+// THE WHOLE TIME-LOOP BODY main.cpp:531-583 FOR THE repwvl PATH IN ONE KERNEL -- built, measured, NOT the production
+// path: test-side build only (-DRCM_WITH_VARIANTS; DESIGN.md 5 has the numbers).  10 000 x Reduced100: 525 us per
+// step against 400 us for k_pre + k_rt_repwvl_flat + k_post.  Whole-column ownership cuts the work into 5 000
+// waves of 7 passes for 3 072 wave slots; the second "round" leaves 37 % of the chip idle (a lone wave is latency
+// bound: it takes as long per pass as one of three), and a pass of this kernel is no faster than a pass of the
+// flattened one.  Kept because it is a complete second implementation of the step that the tests compare with
+// the oracle and with the three-kernel path.
 //
 // A wave OWNS K = 32/LPC columns for the whole launch and runs `nsteps` iterations on them without leaving the
 // kernel: columns are independent (no horizontal coupling anywhere in main.cpp), so nothing but the wave itself
@@ -1040,9 +1092,9 @@ __global__ __launch_bounds__(64, RCM_PAIR_LB) void k_step_repwvl(Dev d, int firs
   double *scr = (K * 102 <= (NH + 1) * 64) ? &st[0][0] : reinterpret_cast<double *>(st + (NH + 1));
   const int lane = threadIdx.x;
   const int c0 = blockIdx.x * K;
-  const int p = pair_parity(lane);
-  const int slot = pair_index(lane) / LPC;       // which of the wave's columns this lane pair works for
-  const int j = pair_index(lane) - slot * LPC;   // its index among the column's lane pairs
+  const int p = PairRw::parity(lane);
+  const int slot = PairRw::index(lane) / LPC;       // which of the wave's columns this lane pair works for
+  const int j = PairRw::index(lane) - slot * LPC;   // its index among the column's lane pairs
   const bool col_ok = c0 + slot < d.ncol;
   // lanes of phases A / E: (column q, layer l), three columns per round
   const int aq = lane / NL, al = lane - aq * NL;
@@ -1125,7 +1177,7 @@ __global__ __launch_bounds__(64, RCM_PAIR_LB) void k_step_repwvl(Dev d, int firs
 #pragma unroll
     for (int i = 0; i < NH; ++i) acc2[i] = 0.0;
     for (int w = j; w < d.n_wvl; w += LPC) {
-      // both lanes of a pair share w and col_ok: pair_swap sees both active
+      // both lanes of a pair share w and col_ok: the hand-over sees both active
       if (col_ok) repwvl_pair_point<CUBE>(d, img[slot], p, w, lane, st, acc1, acc2);
       RCM_STAMP(8 + (w - j) / LPC);
     }
@@ -1135,12 +1187,12 @@ __global__ __launch_bounds__(64, RCM_PAIR_LB) void k_step_repwvl(Dev d, int firs
     __syncthreads();  // the staging columns are free again: scr may be written
 #pragma unroll
     for (int i = 0; i <= NH; ++i) {
-      const double v = pair_sum<kLog2Lpc>(acc1[i]);
+      const double v = PairRw::sum<kLog2Lpc>(acc1[i]);
       if (j == 0 && col_ok) (scr + (size_t)slot * 102 + 2 * NL)[p ? NLEV + NL - i : i] = v;
     }
 #pragma unroll
     for (int k = 0; k < NH; ++k) {
-      const double v = pair_sum<kLog2Lpc>(acc2[k]);
+      const double v = PairRw::sum<kLog2Lpc>(acc2[k]);
       if (j == 0 && col_ok) (scr + (size_t)slot * 102 + 2 * NL)[p ? NL - k : NLEV + k] = v;
     }
     __syncthreads();
@@ -1193,6 +1245,8 @@ __global__ __launch_bounds__(64, RCM_PAIR_LB) void k_step_repwvl(Dev d, int firs
     RCM_STAMP(5);
   }
 }
+
+#endif  // RCM_WITH_VARIANTS (k_step_repwvl)
 
 // ---------------------------------------------------------------------------------------------
 // Convective adjustment: theta = T*conv, sort descending, T = theta/conv (main.cpp:123-139,
@@ -1406,13 +1460,14 @@ __global__ __launch_bounds__(64) void k_tau_pair(Dev d, int col, double *out) {
     RepwvlPairLds rw;
   } img;
   __shared__ double st[NH + 1][64];
-  const int lane = threadIdx.x, p = pair_parity(lane);
+  const int lane = threadIdx.x;
+  const int p = d.mode == MODE_REPWVL ? PairRw::parity(lane) : PairLbl::parity(lane);
   if (d.mode == MODE_REPWVL)
     repwvl_pair_image(d, col, lane, img.rw);
   else
     lbl_pair_image(d, col, lane, img.lbl);
   __syncthreads();
-  const long b = (long)blockIdx.x * 32 + pair_index(lane);
+  const long b = (long)blockIdx.x * 32 + (d.mode == MODE_REPWVL ? PairRw::index(lane) : PairLbl::index(lane));
   if (b >= d.nspec) return;
   if (d.mode == MODE_REPWVL) {
     repwvl_pair_tau(d, img.rw, p, (int)b, st, lane);

@@ -40,9 +40,10 @@ def _columns(inp, idx):
     return out
 
 
-def _compare_sampled(pkg, olib, inp, idx, steps, fusion=-1):
-    g = H.gpu_ensemble(pkg, inp)
-    g.set_step_fusion(fusion)
+def _compare_sampled(pkg, olib, inp, idx, steps, library=None, fusion=-1):
+    g = H.gpu_ensemble(pkg, inp, library=library)
+    if fusion != -1:
+        g.set_step_fusion(fusion)
     o = H.oracle_ensemble(olib, _columns(inp, idx))
     g.step(steps), o.step(steps)
     fg, fo, sg, so = g.get_fluxes(), o.get_fluxes(), g.get_state(), o.get_state()
@@ -66,16 +67,17 @@ def _compare_sampled(pkg, olib, inp, idx, steps, fusion=-1):
     return fg, sg
 
 
-def test_config2_10000_columns_reduced100_sampled_against_oracle(pkg, olib):
-    """BASELINE configs[2] at size: 10 000 columns (CO2 x RH x T_surface perturbed) x Reduced100, 2 steps."""
+def test_config2_10000_columns_reduced100_sampled_against_oracle(pkg, olib, variants):
+    """BASELINE configs[2] at size: 10 000 columns (CO2 x RH x T_surface perturbed) x Reduced100, 2 steps: the
+    production path (k_pre, 31 250 waves of k_rt_repwvl_flat in 7 813 blocks, k_post over 10 000 columns) -- what
+    `bench.py --workload repwvl100` runs -- and the test-side fused whole-step kernel at the same size."""
     inp = H.make_inputs(pkg, "repwvl", 10000, table="Reduced100")
     idx = [0, 1, 2, 3, 3333, 4999, 5000, 7777, 9996, 9997, 9998, 9999]  # incl. the first and the last block
     g = H.gpu_ensemble(pkg, inp)
-    assert g.get_step_fusion() == 16  # the fused whole-step kernel, 2 columns per wave: what the bench runs
+    assert g.get_step_fusion() == 0 and g.get_spectral_chunks() == 5  # flattened kernel, 5 record slots per column
     g.close()
     _compare_sampled(pkg, olib, inp, idx, steps=2)
-    # ... and the three-kernel path at the same size (31 250 flattened waves, k_post over 10 000 columns)
-    _compare_sampled(pkg, olib, inp, idx, steps=2, fusion=0)
+    _compare_sampled(pkg, olib, inp, idx, steps=2, library=variants, fusion=1)
 
 
 def test_lbl_2000_columns_big_ensemble_chunk_branch_sampled_against_oracle(pkg, olib):
@@ -98,9 +100,10 @@ def test_config3_10000_columns_full_lbl_spectrum_sampled_against_oracle(pkg, oli
     _compare_sampled(pkg, olib, inp, [0, 4999, 9999], steps=2)
 
 
-# ---- the fused whole-step kernel of the repwvl path (k_step_repwvl) --------------------------------
+# ---- the fused whole-step kernel of the repwvl path (k_step_repwvl; TEST-SIDE build: measured slower than the
+# three-kernel path, kept as a second complete implementation of the step) ------------------------------------
 @pytest.mark.parametrize("table", ["Reduced10", "Reduced20", "Reduced100"])
-def test_fused_step_kernel_against_oracle_ragged_sizes(pkg, olib, table):
+def test_fused_step_kernel_against_oracle_ragged_sizes(pkg, olib, variants, table):
     """k_step_repwvl forced on for small ensembles: every lane-pairs-per-column choice the cost model makes for
     these sizes, waves whose last columns do not exist (ncol not a multiple of the columns per wave), several
     iterations inside ONE launch (incl. the first one with its pre-adjustment optical depths, main.cpp:500)."""
@@ -108,7 +111,7 @@ def test_fused_step_kernel_against_oracle_ragged_sizes(pkg, olib, table):
     for ncol in (1, 2, 3, 5, 7, 33, 130):
         inp = H.make_inputs(pkg, "repwvl", ncol, table=table)
         inp["cols"]["Tlayer0"][ncol // 2, 15] += 25.0  # one unstable column: the sort reorders its layers
-        g, o = H.gpu_ensemble(pkg, inp), H.oracle_ensemble(olib, inp)
+        g, o = H.gpu_ensemble(pkg, inp, library=variants), H.oracle_ensemble(olib, inp)
         g.set_step_fusion(1)
         seen.add(g.get_step_fusion())
         g.step(1), o.step(1)
@@ -132,14 +135,17 @@ def test_fused_step_kernel_against_oracle_ragged_sizes(pkg, olib, table):
     assert len(seen) >= 1 and all(2 <= v <= 32 for v in seen), seen
 
 
-def test_fused_and_three_kernel_paths_agree_and_interleave(pkg, olib, tmp_path):
+def test_fused_and_three_kernel_paths_agree_and_interleave(pkg, olib, variants, tmp_path):
     """The same ensemble stepped by k_step_repwvl and by k_pre + k_rt_repwvl_flat + k_post: equal to the order of the
     spectral sum; a run may switch between them at any iteration (state lives in the same HBM arrays), also across a
     checkpoint; 600 iterations cross the 512-iterations-per-launch cut."""
     inp = H.make_inputs(pkg, "repwvl", 9, table="Reduced20")
-    a, b, c = (H.gpu_ensemble(pkg, inp) for _ in range(3))
-    a.set_step_fusion(1), b.set_step_fusion(0)
-    assert a.get_step_fusion() > 0 and b.get_step_fusion() == 0 and c.get_step_fusion() == 0  # 9 columns: auto = off
+    a, c = (H.gpu_ensemble(pkg, inp, library=variants) for _ in range(2))
+    b = H.gpu_ensemble(pkg, inp)  # the product: three kernels per iteration, nothing else to select
+    a.set_step_fusion(1)
+    assert a.get_step_fusion() > 0 and b.get_step_fusion() == 0 and c.get_step_fusion() == 0  # automatic = off
+    with pytest.raises(pkg.RcmError):
+        b.set_step_fusion(1)
     a.step(6), b.step(6)
     c.set_step_fusion(1), c.step(2), c.set_step_fusion(0), c.step(3), c.set_step_fusion(1), c.step(1)
     for x in (b, c):
@@ -149,7 +155,7 @@ def test_fused_and_three_kernel_paths_agree_and_interleave(pkg, olib, tmp_path):
         np.testing.assert_array_equal(x.get_state()["time_h"], a.get_state()["time_h"])
     ck = str(tmp_path / "f.ck")
     a.checkpoint_save(ck)
-    d = H.gpu_ensemble(pkg, inp)
+    d = H.gpu_ensemble(pkg, inp, library=variants)
     d.checkpoint_load(ck)
     d.set_step_fusion(1)
     a.step(600), d.step(600)
@@ -160,15 +166,15 @@ def test_fused_and_three_kernel_paths_agree_and_interleave(pkg, olib, tmp_path):
     assert H.max_abs(a.get_state()["T_surface"], o.get_state()["T_surface"]) <= 1e-6
 
 
-def test_fused_equilibrium_and_nan_column(pkg, olib):
+def test_fused_equilibrium_and_nan_column(pkg, olib, variants):
     inp = H.make_inputs(pkg, "repwvl", 6, table="Reduced10")
-    g, o = H.gpu_ensemble(pkg, inp), H.oracle_ensemble(olib, inp)
+    g, o = H.gpu_ensemble(pkg, inp, library=variants), H.oracle_ensemble(olib, inp)
     g.set_step_fusion(1)
     n_g, r_g = g.run_to_equilibrium(0.12, 400, 25)
     n_o, r_o = o.run_to_equilibrium(0.12, 400, 25)
     assert n_g == n_o and 25 <= n_g < 400 and abs(r_g - r_o) <= 1e-9
     inp["cols"]["Tlayer0"][4, 3] = np.nan
-    g = H.gpu_ensemble(pkg, inp)
+    g = H.gpu_ensemble(pkg, inp, library=variants)
     g.set_step_fusion(1)
     g.step(3)
     s = g.get_state()
@@ -315,6 +321,7 @@ def test_two_ranks_with_hip_compute_equal_one_rank(pkg, tmp_path):
 def test_repwvl_bench_workload_contract(pkg):
     d = _bench(["--workload", "repwvl100", "--ncol", "500", "--steps", "5", "--warmup", "1"])
     assert d["config"]["wavelengths"] == 100 and d["roofline"]["kernel"] == "k_rt_repwvl_flat"
+    assert d["roofline"]["launches"] == 5
     assert d["roofline"]["algorithmic_bytes_per_launch"] == (9 * 9 * 41 * 8 + 16) * 100 * 500
     assert d["cpu_baseline"]["kind"] == "port" and d["cpu_baseline"]["single_core_rt_only_value"] > 0
     assert d["cpu_baseline"]["single_core_reread_table_per_step_value"] < d["cpu_baseline"]["single_core_value"]

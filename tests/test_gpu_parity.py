@@ -658,12 +658,14 @@ def test_nan_column_stays_nan_and_isolated(pkg):
     assert np.isnan(s["Tlayer"][1]).all() and np.isnan(s["T_surface"][1])
 
 
-def test_kernel_is_closer_to_long_double_than_the_reference_arithmetic(pkg, olib):
+def test_kernel_distance_from_a_long_double_evaluation_of_the_sweep(pkg, olib):
     """tools/accuracy_vs_longdouble.py: the reference's sweep re-evaluated in long double from the same optical
-    depths and Planck values.  The kernel stays within 5e-12 W/m2 of it and is no farther from it than the CPU
-    oracle (whose running sum over the bands carries the larger rounding error)."""
+    depths and Planck values.  The production kernel (transmissions: degree-7 polynomial for 2^(f/2), squared:
+    7.4e-13 relative) is 1.6e-11 - 1.9e-11 W/m2 from it, the CPU oracle (= the reference's arithmetic: libm exp, one
+    running sum) 0.7e-11 - 1.0e-11: the same order, five orders inside the 1e-6 contract.  (Round 1 shipped the
+    degree-9 polynomial, 7e-13 W/m2, 3.7 % slower; -DRCM_EXP_DEG=8 is 2e-13 at that cost: profiles/README.md.)"""
     import sys
     sys.path.insert(0, os.path.join(H.ROOT, "tools"))
     import accuracy_vs_longdouble as acc
     for eg, eo, ego in acc.run(3000, lambda *_: None):
-        assert eg <= 5e-12 and eg <= eo and ego <= 2e-9
+        assert eg <= 5e-11 and eo <= 5e-11 and ego <= 2e-9, (eg, eo, ego)

@@ -36,6 +36,7 @@ ens = {}
 for name, L in libs.items():
     g = H.gpu_ensemble(pkg, inp, library=L)
     r = H.gpu_ensemble(pkg, inr, library=L)
+    r.set_step_fusion(0)
     g.step(1), r.step(20)
     g.sync(), r.sync()
     g.set_rt_timing(True), r.set_rt_timing(True)

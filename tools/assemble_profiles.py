@@ -19,10 +19,7 @@ wl = sys.argv[2] if len(sys.argv) > 2 else "lbl"
 rnd = sys.argv[3] if len(sys.argv) > 3 else "r02"
 b = json.load(open(f"gpurun_out/bench_{tag}.json"))
 KERNEL = b["roofline"]["kernel"]
-# the PMC runs of a fused kernel cover several steps per launch: counters and times are per LAUNCH there, so they
-# are divided by the steps one launch of the profiled runs covered (profile_session.sh: PM steps / KT steps)
-PM_STEPS = 1 if wl == "lbl" or "k_step" not in KERNEL else 20
-KT_STEPS = 1 if wl == "lbl" or "k_step" not in KERNEL else 200
+PM_STEPS = KT_STEPS = 1
 ncol = b["config"]["columns_total"]
 nspec = b["config"]["bands"] if wl == "lbl" else b["config"]["wavelengths"]
 points = ncol * nspec

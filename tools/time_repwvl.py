@@ -16,10 +16,12 @@ import our_first_climate_model_amd as pkg
 ncol = int(sys.argv[1]) if len(sys.argv) > 1 else 10000
 table = sys.argv[2] if len(sys.argv) > 2 else "Reduced100"
 steps = int(sys.argv[3]) if len(sys.argv) > 3 else 200
+from our_first_climate_model_amd import build as _b
+VLIB = pkg.load_library(_b.build_variants())  # the fused kernel lives in the test-side build
 inp = H.make_inputs(pkg, "repwvl", ncol, table=table)
 nw = inp["table"]["n_wvl"]
-for name, fusion, chunks in (("fused", 1, 0), ("flat", 0, 0), ("chunked", 0, 1), ("auto", -1, 0)):
-    g = H.gpu_ensemble(pkg, inp)
+for name, fusion, chunks in (("fused", 1, 0), ("flat", 0, 0), ("chunked", 0, 1)):
+    g = H.gpu_ensemble(pkg, inp, library=VLIB if fusion == 1 else None)
     g.set_step_fusion(fusion)
     if chunks:
         g.set_spectral_chunks(chunks)
