@@ -4,9 +4,9 @@ radiative-convective steady state on 1..8 MI355X, one rank per GPU.  Every rank 
 columns; one all-reduce(max) of the residual per check keeps the ranks on the same iteration, one
 all-gather of (Tlayer[20], T_surface) ends the run.
 
-    python examples/equilibrium_ensemble.py --ncol 1000 --tol 0.05
+    python examples/equilibrium_ensemble.py --ncol 12500 --tol 0.01 --max-steps 1500      (one GPU's share)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 \\
-        examples/equilibrium_ensemble.py --ncol 100000 --tol 0.02 --max-steps 400
+        examples/equilibrium_ensemble.py --ncol 100000 --tol 0.01 --max-steps 1500
 
 Needs an MI355X per rank (the product has no CPU path).  Spectra are the seeded synthetic stand-in for the
 absent lbl.*.asc files (our_first_climate_model_amd.synth_lbl_tables)."""
@@ -27,6 +27,7 @@ def main():
     ap.add_argument("--tol", type=float, default=0.05, help="K per iteration on the adjusted profile, worst column")
     ap.add_argument("--max-steps", type=int, default=1000)
     ap.add_argument("--check-every", type=int, default=10)
+    ap.add_argument("--progress", type=int, default=50, help="stderr line every so many iterations (0: none)")
     a = ap.parse_args()
 
     import numpy as np
@@ -48,15 +49,17 @@ def main():
     spec = rcm.perturbation_sweep(hi - lo, perturb_rh=True, perturb_ts=True, first=lo, total=a.ncol)
     cols = rcm.build_columns(atm, spec, "lbl")
     wvl, tabs = rcm.synth_lbl_tables(a.nodes, plevel=cols["plevel"])
-    ens = rcm.Ensemble(hi - lo, device=dev, stream=torch.cuda.current_stream().cuda_stream)
-    ens.set_grid(cols["plevel"])
-    ens.set_forcing(rcm.default_solar()["solar_irr"])
-    ens.set_lbl_tables(wvl, tabs, cols["h2o_ref"])
-    ens.set_columns(cols["Tlayer0"], cols["T_surface0"], cols["gas"], cols["rel_hum"])
+    inp = dict(mode="lbl", ncol=hi - lo, cols=cols, solar=rcm.default_solar()["solar_irr"], wvl=wvl, tabs=tabs)
+    ens = rcm.configure(rcm.Ensemble(hi - lo, device=dev, stream=torch.cuda.current_stream().cuda_stream), inp)
 
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    steps, resid = run_to_equilibrium(ens, a.tol, a.max_steps, a.check_every, dist)
+    def progress(done, worst):
+        if rank == 0 and a.progress and done % a.progress == 0:
+            print(f"[equilibrium] {done} iterations, worst residual {worst:.4f} K/iteration, "
+                  f"{time.perf_counter() - t0:.0f} s", file=sys.stderr, flush=True)
+
+    steps, resid = run_to_equilibrium(ens, a.tol, a.max_steps, a.check_every, dist, progress)
     packed = torch.empty((hi - lo, 21), dtype=torch.float64, device="cuda")
     ens.pack_state(packed.data_ptr())
     ens.sync()

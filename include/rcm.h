@@ -212,7 +212,8 @@ int rcm_default_solar(double out[7]);
 
 /* ASCII_file2xy2D (lbl.arts/ascii.cpp:1631-1691, ascii.h:34-38,63): whitespace matrix with '%'
  * or '#' comments; x = first column [nx], y = remaining columns, returned FLAT [nx][ny]
- * (malloc'd; free with rcm_free).  Returns the reference's codes: 0, -1 file not found,
+ * (malloc'd; free with rcm_free).  Lines are read with the reference's 1 MiB fgets buffer (ascii.cpp:155,255:
+ * a longer physical line continues as the next row).  Returns the reference's codes: 0, -1 file not found,
  * -2 no memory, -5 not a rectangular matrix. */
 int rcm_ascii_file2xy2D(const char *path, int *nx, int *ny, double **x, double **y);
 

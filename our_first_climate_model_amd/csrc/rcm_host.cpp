@@ -172,10 +172,17 @@ int rcm_ascii_file2xy2D(const char *path, int *nx, int *ny, double **x, double *
     return fail(-1, std::string("file not found: ") + path);      // ASCIIFILE_NOT_FOUND
   }
   std::vector<double> vals;
-  char *line = nullptr;
-  size_t cap = 0;
+  // the reference reads with fgets(line, MAX_LENGTH_OF_LINE, f) (ascii.cpp:155,233,255): a physical line of
+  // 1 048 575 characters or more is cut there and continues as the next "row" (a number across the cut splits
+  // in two); same buffer size and same call here so that such a file fails or parses exactly as it does there
+  constexpr int kMaxLine = 1048576;
+  char *line = (char *)std::malloc((size_t)kMaxLine + 1);
+  if (!line) {
+    std::fclose(f);
+    return fail(-2, "no memory");  // ASCII_NO_MEMORY
+  }
   int rows = 0, min_col = INT_MAX, max_col = 0;
-  while (getline(&line, &cap, f) >= 0) {
+  while (std::fgets(line, kMaxLine, f) != nullptr) {
     int ncol = 0;
     char *save = nullptr;
     for (char *tok = strtok_r(line, " \t\n", &save); tok; tok = strtok_r(nullptr, " \t\n", &save)) {

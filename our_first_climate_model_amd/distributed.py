@@ -32,13 +32,14 @@ def gather_state(local_packed, ncol_total, world, dist=None):
     return recv[:ncol_total]
 
 
-def run_to_equilibrium(ens, tol_K, max_steps, check_every=10, dist=None):
+def run_to_equilibrium(ens, tol_K, max_steps, check_every=10, dist=None, progress=None):
     """Steps every rank's shard `check_every` iterations at a time until the WORST column of the whole
     ensemble has a residual <= tol_K (rcm_get_residual: change of the adjusted profile per iteration)
     or max_steps have run: one all-reduce(max) of one double per check, so all ranks stop after the
     same number of iterations and the gathered state is one consistent iteration of the ensemble
     (BASELINE configs[4]).  Returns (steps_done, worst_residual_K).
-    `ens` needs step(n) and get_residual() (our_first_climate_model_amd.Ensemble)."""
+    `ens` needs step(n) and get_residual() (our_first_climate_model_amd.Ensemble); `progress(done, worst)` is called
+    after every check.  A NaN residual anywhere (a column gone NaN) never counts as converged."""
     import torch
     if dist is None:
         import torch.distributed as dist
@@ -49,12 +50,17 @@ def run_to_equilibrium(ens, tol_K, max_steps, check_every=10, dist=None):
         ens.step(n)
         done += n
         r = ens.get_residual()
-        worst = float(np.max(r)) if len(r) else 0.0  # an empty shard never holds the others back
+        worst = (float("nan") if np.isnan(r).any() else float(np.max(r))) if len(r) else 0.0  # an empty shard never holds the others back
         if multi:
             backend = dist.get_backend()
-            t = torch.tensor([worst], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
+            # (max over ranks is not NaN-propagating in every backend: the NaN travels as a flag)
+            nan = worst != worst
+            t = torch.tensor([0.0 if nan else worst, 1.0 if nan else 0.0], dtype=torch.float64,
+                             device="cuda" if backend == "nccl" else "cpu")
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            worst = float(t.item())
+            worst = float("nan") if float(t[1]) > 0 else float(t[0])
+        if progress is not None:
+            progress(done, worst)
         if worst <= tol_K:
             break
     return done, worst
