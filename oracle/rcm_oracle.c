@@ -7,6 +7,11 @@
  * reference built with `g++ -O2` (no FMA contraction on baseline x86-64).
  *
  * The reference is /root/reference (pabloconrat/our_first_climate_model).
+ *
+ * PARITY UNPINNED for the hot functions (Planck, sweep, read_tau, time step): main.cpp and
+ * repwvl_thermal.cpp need <netcdf>, absent from this image, and the reference holds no flux
+ * fixture; pinned are the t = 0 rows / solar banners of output.txt and, against the compiled
+ * reference, cplkavg and the ASCII loader (rcm_oracle.h, oracle/README.md).
  */
 #define _GNU_SOURCE
 #include "rcm_oracle.h"

@@ -10,8 +10,9 @@
  *
  * Parity pinning (see oracle/README.md, DESIGN.md section "Oracle"):
  *   - solar known answers and the t=0 rows from the reference's output.txt,
- *   - the [probe] outputs of the unmodified reference recorded in
- *     SURVEY.md section 8(c) (tests/golden/survey_probe.json),
+ *   - PARITY UNPINNED for Planck / sweep / read_tau / time step: the [probe]
+ *     outputs recorded in SURVEY.md section 8(c) (tests/golden/survey_probe.json), which this file
+ *     reproduces bit for bit, come from a build with a stand-in <netcdf> header and pin nothing,
  *   - cplkavg.cpp known answers + the reference cplkavg.cpp compiled as-is
  *     into oracle/_ref/ (it needs only libm),
  *   - the reference ascii.cpp compiled as-is into oracle/_ref/.
