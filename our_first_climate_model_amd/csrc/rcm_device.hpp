@@ -191,30 +191,50 @@ __device__ __forceinline__ double div_by_t(double c, double t, double rT) {
 
 // exp(x) for the Planck argument, 0 < x < 700: same construction as exp_trans (base-2 reduction in
 // one FMA, degree-10 polynomial 5.8e-16, v_ldexp_f64), no clamps needed in that range.
+#ifndef RCM_EXPPOS_HALF
+#define RCM_EXPPOS_HALF 1  // 1: degree 8 for 2^(f/2), squared (7.1e-15; one instruction fewer than 0: degree 10, 5.8e-16)
+#endif
+#ifndef RCM_RCP_NEWTON
+#define RCM_RCP_NEWTON 1   // Newton steps after v_rcp_f64 (~2^-26 relative) in the Planck functions: one reaches ~2^-52
+#endif
 __device__ __forceinline__ double exp_pos(double x) {
   constexpr double kLog2e = 0x1.71547652b82fep+0;
   constexpr double kMagic = 0x1.8p+52;
   const double z = fma(x, kLog2e, kMagic);
   const double kf = z - kMagic;
   const double f = fma(x, kLog2e, -kf);
+#if RCM_EXPPOS_HALF
+  double q = kExp2Half8[8];
+#pragma unroll
+  for (int i = 7; i >= 0; --i) q = fma(q, f, kExp2Half8[i]);
+  q *= q;
+#else
   double q = kExp2Poly10[10];
 #pragma unroll
   for (int i = 9; i >= 0; --i) q = fma(q, f, kExp2Poly10[i]);
+#endif
   return __builtin_amdgcn_ldexp(q, __double2loint(z));
+}
+
+// 1/d from v_rcp_f64 (~2^-26 relative) and RCM_RCP_NEWTON Newton steps (each squares the error)
+__device__ __forceinline__ double rcp_newton(double d) {
+  double g = __builtin_amdgcn_rcp(d);
+#pragma unroll
+  for (int i = 0; i < RCM_RCP_NEWTON; ++i) g = fma(fma(-d, g, 1.0), g, g);
+  return g;
 }
 
 // The fast formula itself, preconditions established by the caller: xm = argument at the band centre,
 // hh = its width.
 __device__ __forceinline__ double cplkavg_fast_mid(double xm, double hh, double pc) {
   const double d = exp_pos(xm) - 1.0;
-  double g = __builtin_amdgcn_rcp(d);  // ~2^-26 relative; two Newton steps reach full precision
-  g = fma(fma(-d, g, 1.0), g, g);
-  g = fma(fma(-d, g, 1.0), g, g);
+  const double g = rcp_newton(d);
   const double g1 = fma(-g, g, -g);          // dg/dx = -g(1+g)
   const double g2 = -g1 * fma(2.0, g, 1.0);  // d2g/dx2
   const double x2 = xm * xm, x3 = x2 * xm;
   const double f = x3 * g;
-  const double f2 = fma(x3, g2, fma(6.0 * x2, g1, 6.0 * xm * g));
+  // f2 = x^3 g2 + 6 x^2 g1 + 6 x g = x * (x^2 g2 + 6 (x g1 + g))
+  const double f2 = xm * fma(x2, g2, 6.0 * fma(xm, g1, g));
   return pc * (hh * fma(hh * hh * (1.0 / 24.0), f2, f));
 }
 
@@ -233,10 +253,7 @@ __device__ __forceinline__ bool cplkavg_fast(double c2lo, double c2hi, double t,
 
 __device__ __forceinline__ double planck_mono_fast(double xc, double sc, double T, double rT) {
   const double d = exp_pos(div_by_t(xc, T, rT)) - 1.0;
-  double g = __builtin_amdgcn_rcp(d);
-  g = fma(fma(-d, g, 1.0), g, g);
-  g = fma(fma(-d, g, 1.0), g, g);
-  return sc * g;
+  return sc * rcp_newton(d);
 }
 
 // Magnus saturation vapour pressure [hPa]: main.cpp:277-279

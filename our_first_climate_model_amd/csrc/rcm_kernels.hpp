@@ -39,6 +39,11 @@ constexpr int WPB = 4;       // waves per block = columns per block (one per SIM
 #ifndef RCM_PAIR_PLK_UNROLL
 #define RCM_PAIR_PLK_UNROLL 3  // band-Planck evaluations in flight in the branch-free loop of the lane-pair lbl kernel
 #endif
+#ifndef RCM_PLK_XM_FAST
+#define RCM_PLK_XM_FAST 1  // band-centre Planck argument as c2mid * (1/T) (two roundings: <= 1.5e-14 relative in B at x = 60,
+#endif                     // 1e-15 at the 10 um peak) instead of the correctly rounded quotient: 2 FMAs per value.
+                           // Measured (tools/ab_planck.py): with one Newton step and the half-range exp_pos -1.9 % kernel
+                           // time, narrow-band slice and full-range deviations from the oracle unchanged (3.1e-13, 2.1e-11)
 #ifndef RCM_PLK_UNROLL
 #define RCM_PLK_UNROLL 1  // independent band-Planck evaluations in flight
 #endif
@@ -726,7 +731,12 @@ __global__ __launch_bounds__(64 * WPB, RCM_PAIR_LB) void k_rt_lbl_pair(Dev d) {
 #pragma unroll RCM_PAIR_PLK_UNROLL
       for (int k = 0; k <= NH; ++k) {
         const double t = s.T[p][k], rT = s.rT[p][k];
+#if RCM_PLK_XM_FAST  // x at the band centre as c2mid * (1/T): two roundings instead of the correctly rounded quotient
+        (void)t;
+        st[k][lane] = cplkavg_fast_mid(c2mid * rT, dc2 * rT, s.pc[p][k]);
+#else
         st[k][lane] = cplkavg_fast_mid(div_by_t(c2mid, t, rT), dc2 * rT, s.pc[p][k]);
+#endif
       }
     } else {
 #pragma unroll 1
