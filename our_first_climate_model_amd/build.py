@@ -41,7 +41,7 @@ def build_variants(force=False):
     srcs, deps, common = _sources()
     if force or _newer(VARIANTS_LIB, deps):
         os.makedirs(os.path.dirname(VARIANTS_LIB), exist_ok=True)
-        subprocess.run([HIPCC] + common + ["-DRCM_WITH_VARIANTS", "-DRCM_FLAT_G2_MIN_GROUPS=8", "-shared", "-o", VARIANTS_LIB] + srcs, check=True)
+        subprocess.run([HIPCC] + common + ["-DRCM_WITH_VARIANTS", "-shared", "-o", VARIANTS_LIB] + srcs, check=True)
     return VARIANTS_LIB
 
 

@@ -15,9 +15,6 @@
 #include "rcm_internal.hpp"
 #include "rcm_kernels.hpp"
 
-#ifndef RCM_FLAT_G2_MIN_GROUPS
-#define RCM_FLAT_G2_MIN_GROUPS (3L * 4096)  // smaller ensembles keep one group per wave: they need the waves to fill the chip
-#endif                                      // (the test-side build sets 8 so that small tests run the two-group path too)
 #ifndef RCM_GEN15
 #define RCM_GEN15 1  // root pairs 3m / 5m from one exponential (0: every root its own)
 #endif
@@ -180,7 +177,7 @@ constexpr int kPostSlices = 32;  // blocks per column of the first-stage chunk s
 
 bool use_flat(const rcm_ensemble *h) {
   return h->mode == rcm::MODE_REPWVL && h->flat && h->pair && h->exp_variant == 1 && h->user_chunks == 0 &&
-         h->d.n_wvl >= 8;  // at most 255/8 + 2 = 33 column images per block (125 KB)
+         h->d.n_wvl >= 8;  // at most 127/8 + 2 = 17 column images per block (45 KB)
 }
 
 #ifdef RCM_WITH_VARIANTS
@@ -241,17 +238,14 @@ void launch_rt_pair(rcm_ensemble *h, int blocks) {
   if (h->mode == rcm::MODE_LBL) {
     hipLaunchKernelGGL((rcm::k_rt_lbl_pair<CUBE>), dim3(blocks), dim3(64 * rcm::WPB), 0, h->stream, h->d);
   } else if (use_flat(h)) {
-    // groups of 32 items; the first ~85 % of a big ensemble in blocks of 8 groups (2 per wave), the rest and small
-    // ensembles in blocks of 4 (1 per wave): long waves amortise, short ones fill the tail of the launch
-    const long groups = ((long)h->ncol * h->d.n_wvl + 31) / 32;
-    const long nb2 = groups >= RCM_FLAT_G2_MIN_GROUPS ? (groups * 85 / 100) / (2 * rcm::WPB) : 0;
-    const long nb1 = (groups - nb2 * 2 * rcm::WPB + rcm::WPB - 1) / rcm::WPB;
-    const int maxc = (rcm::WPB * 32 * (nb2 ? 2 : 1) - 1) / h->d.n_wvl + 2;  // columns the items of a block can touch
+    const int maxc = (rcm::WPB * 32 - 1) / h->d.n_wvl + 2;  // columns the 128 consecutive items of a block can touch
     const size_t lds = (size_t)maxc * sizeof(rcm::RepwvlPairLds) + (size_t)rcm::WPB * (rcm::NH + 1) * 64 * sizeof(double);
+    const long waves = ((long)h->ncol * h->d.n_wvl + 31) / 32;
     const auto kern = rcm::k_rt_repwvl_flat<CUBE>;
     if (lds > 48 * 1024)
       (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL(kern, dim3((unsigned)(nb2 + nb1)), dim3(64 * rcm::WPB), lds, h->stream, h->d, maxc, (int)nb2);
+    hipLaunchKernelGGL(kern, dim3((unsigned)((waves + rcm::WPB - 1) / rcm::WPB)), dim3(64 * rcm::WPB), lds, h->stream,
+                       h->d, maxc);
   } else {
     hipLaunchKernelGGL((rcm::k_rt_repwvl_pair<CUBE>), dim3(blocks), dim3(64 * rcm::WPB), 0, h->stream, h->d);
   }

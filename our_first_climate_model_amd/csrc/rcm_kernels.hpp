@@ -915,150 +915,83 @@ __global__ __launch_bounds__(64 * WPB, RCM_PAIR_LB) void k_rt_repwvl_pair(Dev d)
 }
 
 // ---------------------------------------------------------------------------------------------
-// The same, with the (column, wavelength) pairs FLATTENED over the lane pairs: the column-major item list is cut
-// into GROUPS of 32 consecutive items, whichever columns they belong to, and a wave takes G consecutive groups
-// (G = 2 for the bulk of a big ensemble, 1 for its last ~15 % and for small ensembles).  100 wavelengths fill
-// 100/128 of the lane pairs in the chunked kernel, 10 wavelengths 10/32; here every pass is full, and the work comes
-// in equal small pieces (whole-column ownership leaves the last third of the run to a partly empty chip, measured
-// with k_step_repwvl).  What a wave does besides its passes is kept small:
-//  * the column images are shared by the block: its 4 waves cover 128*G consecutive items = at most
-//    (128*G-1)/n_wvl + 2 columns, one image each, built by the 4 waves in parallel;
-//  * the optical depths of the wave's G items are formed TOGETHER (twice the table loads in flight: the stage is
-//    latency-bound, 2.6k cycles per layer measured), then each item runs Planck, angles and its reduction;
+// The same, with the (column, wavelength) pairs FLATTENED over the lane pairs: wave i takes the 32
+// consecutive items 32i..32i+31 of the column-major list, whichever columns they belong to.  100 wavelengths
+// fill 100/128 of the lane pairs in the chunked kernel, 10 wavelengths 10/32; here every pass is full, and the
+// work comes in 31 250 equal pieces for 10 000 x 100 (whole-column ownership leaves the last third of the run
+// to a partly empty chip, measured with k_step_repwvl).  What a wave does besides its one pass is kept small:
+//  * the column images are shared by the block: its 4 waves cover 128 consecutive items = at most 127/n_wvl + 2
+//    columns, one image each, built by the 4 waves in parallel (before: every wave built its own two);
 //  * the per-column sums are MASKED BUTTERFLIES over the lanes (a lane contributes its sums to the column its
-//    item belongs to and zero to the others), not serial loops through LDS.
+//    item belongs to and zero to the others), not serial loops through LDS;
+//  * 30.5 KB of LDS per block and <= 128 VGPRs: 4 waves per SIMD.
 // A column's partial record goes to slot ceil((first item of the segment - first item of the column)/32), so
 // records never collide and the slots a column never uses stay zero (the buffer is zeroed once).
 // d.nchunk = number of slots.
 // ---------------------------------------------------------------------------------------------
 #ifndef RCM_FLAT_LB
-#define RCM_FLAT_LB 3  // waves per SIMD k_rt_repwvl_flat is register-allocated for
+#define RCM_FLAT_LB 4  // waves per SIMD k_rt_repwvl_flat is register-allocated for
 #endif
-
-// Optical depths (repwvl_pair_tau's arithmetic) of G items at once, into registers.
-template <int G>
-__device__ __forceinline__ void repwvl_pair_tau_multi(const Dev &d, const RepwvlPairLds *const (&img)[G], int p,
-                                                      const int (&w)[G], double (&tau)[G][NH]) {
-  const unsigned ld8 = (unsigned)d.n_wvl * 8u;
-  const char *bA = (const char *)d.xp, *bB = bA + (size_t)d.n_species * ld8;
-#pragma unroll
-  for (int k = 0; k < NH; ++k) {
-#pragma unroll
-    for (int i = 0; i < G; ++i) {
-      const RepwvlPairLds &s = *img[i];
-      const unsigned vo = s.xoff[p][k] + (unsigned)w[i] * 8u;
-      double a = 0.0;
-#pragma unroll
-      for (int sp = 0; sp < RCM_NSPEC_REPWVL; ++sp) {
-        if (!((d.species_mask >> sp) & 1u)) continue;  // vmr == 0 everywhere: the term is +0
-        const unsigned v = vo + (unsigned)sp * ld8;
-        a = fma(s.cA[p][sp][k], *(const double *)(bA + v), fma(s.cB[p][sp][k], *(const double *)(bB + v), a));
-      }
-      tau[i][k] = clamp_tau(a + s.cloud[p][k]);
-    }
-  }
-}
-
-// The groups first_group + wib*G .. +G-1 of one wave.  imgs = the block's column images, first column cb_first.
-template <int CUBE, int G>
-__device__ __forceinline__ void flat_wave(const Dev &d, const RepwvlPairLds *imgs, int cb_first, long first_group,
-                                          int lane, double (*st)[64]) {
-  const int p = PairRw::parity(lane);
-  const long nw = d.n_wvl;
-  const long nflat = (long)d.ncol * nw;
-  long flat[G];
-  int col[G], w[G];
-  const RepwvlPairLds *img[G];
-#pragma unroll
-  for (int i = 0; i < G; ++i) {
-    flat[i] = (first_group + i) * 32 + PairRw::index(lane);
-    const bool ok = flat[i] < nflat;
-    const long f = ok ? flat[i] : nflat - 1;  // lanes beyond the list compute on the last item and contribute nothing
-    const int c = (int)(f / nw);
-    col[i] = ok ? c : -1;
-    w[i] = (int)(f - (long)c * nw);
-    img[i] = imgs + (c - cb_first);
-  }
-  RCM_PT_STAMP(20);
-  double tau[G][NH];
-  repwvl_pair_tau_multi<G>(d, img, p, w, tau);
-  RCM_PT_STAMP(21);
-  const bool w0 = lane == PairRw::lane_of(0, 0), w1 = lane == PairRw::lane_of(0, 1);
-#pragma unroll
-  for (int i = 0; i < G; ++i) {
-    const long flat0 = (first_group + i) * 32;
-    if (flat0 >= nflat) break;  // (whole wave)
-    const RepwvlPairLds &s = *img[i];
-    const double xc = d.rw_xc[w[i]];  // h*c/(lambda*kB), main.cpp:70-72,191
-    const double sc = d.rw_sc[w[i]];  // weight*2*h*c^2/lambda^5/1e9, main.cpp:190-191
-    double B[NH];
-#pragma unroll
-    for (int k = 0; k < NH; ++k) B[k] = planck_mono_fast(xc, sc, s.T[p][k], s.rT[p][k]);
-    const double Linit = p ? planck_mono_fast(xc, sc, s.T[p][NH], s.rT[p][NH]) : 0.0;
-    double acc1[NH + 1], acc2[NH];
-#pragma unroll
-    for (int j = 0; j <= NH; ++j) acc1[j] = 0.0;  // main.cpp:326-327
-#pragma unroll
-    for (int j = 0; j < NH; ++j) acc2[j] = 0.0;
-    RCM_PT_STAMP(22);
-    pair_all_angles<PairRw, CUBE>(d, tau[i], B, Linit, st, lane, acc1, acc2);
-    RCM_PT_STAMP(23);
-    // ---- segmented reduction: one masked butterfly per column of the group's 32 items (fixed order)
-    // even lane: acc1[j] = E_down[j] (j = 0..10), acc2[k] = E_up[k] (k = 0..9)
-    // odd lane:  acc1[j] = E_up[20-j],           acc2[k] = E_down[20-k]
-    const int c_first = (int)(flat0 / nw), c_last = (int)(min(flat0 + 31, nflat - 1) / nw);
-    for (int c = c_first; c <= c_last; ++c) {
-      const bool mine = col[i] == c;
-      const long seg0 = max((long)c * nw, flat0);
-      const long slot = (seg0 - (long)c * nw + 31) / 32;
-      double *oEd = d.partial + ((size_t)c * d.nchunk + slot) * PSTRIDE, *oEu = oEd + NLEV;
-#pragma unroll
-      for (int j = 0; j <= NH; ++j) {
-        const double v = PairRw::sum<5>(mine ? acc1[j] : 0.0);
-        if (w0) oEd[j] = v;
-        if (w1) oEu[NL - j] = v;
-      }
-#pragma unroll
-      for (int k = 0; k < NH; ++k) {
-        const double v = PairRw::sum<5>(mine ? acc2[k] : 0.0);
-        if (w0) oEu[k] = v;
-        if (w1) oEd[NL - k] = v;
-      }
-    }
-  }
-  RCM_PT_STAMP(18);
-}
-
-// Blocks 0 .. nb2-1 take 8 groups each (2 per wave), the others 4 (1 per wave).
 template <int CUBE>
-__global__ __launch_bounds__(64 * WPB, RCM_FLAT_LB) void k_rt_repwvl_flat(Dev d, int maxc, int nb2) {
+__global__ __launch_bounds__(64 * WPB, RCM_FLAT_LB) void k_rt_repwvl_flat(Dev d, int maxc) {
   extern __shared__ __align__(16) unsigned char s_dyn[];
   const int lane = threadIdx.x & 63;
   const int wib = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   RepwvlPairLds *imgs = reinterpret_cast<RepwvlPairLds *>(s_dyn);  // the block's columns
   double(*st)[64] = reinterpret_cast<double(*)[64]>(s_dyn + (size_t)maxc * sizeof(RepwvlPairLds) +
                                                     (size_t)wib * (NH + 1) * 64 * sizeof(double));
+  const int p = PairRw::parity(lane);
   const long nw = d.n_wvl;
   const long nflat = (long)d.ncol * nw;
-  const bool two = (int)blockIdx.x < nb2;  // block-uniform
-  const int G = two ? 2 : 1;
-  const long group0 = two ? (long)blockIdx.x * (2 * WPB) : (long)nb2 * (2 * WPB) + (long)((int)blockIdx.x - nb2) * WPB;
-  const long blk0 = group0 * 32, blk_items = (long)WPB * 32 * G;
+  const long blk0 = (long)blockIdx.x * (WPB * 32);
+  const long flat0 = blk0 + wib * 32;
   int cb_first = 0, ncb = 0;  // first column and number of columns the block touches
   if (blk0 < nflat) {
     cb_first = (int)(blk0 / nw);
-    ncb = (int)(min(blk0 + blk_items - 1, nflat - 1) / nw) - cb_first + 1;
+    ncb = (int)(min(blk0 + WPB * 32 - 1, nflat - 1) / nw) - cb_first + 1;
   }
   RCM_PT_STAMP(16);
   for (int sl = wib; sl < ncb; sl += WPB) repwvl_pair_image(d, cb_first + sl, lane, imgs[sl]);
   __syncthreads();
   RCM_PT_STAMP(17);
-  const long first_group = group0 + (long)wib * G;
-  if (first_group * 32 >= nflat) return;  // (whole wave)
-  if (two)
-    flat_wave<CUBE, 2>(d, imgs, cb_first, first_group, lane, st);
-  else
-    flat_wave<CUBE, 1>(d, imgs, cb_first, first_group, lane, st);
+
+  double acc1[NH + 1], acc2[NH];
+#pragma unroll
+  for (int j = 0; j <= NH; ++j) acc1[j] = 0.0;
+#pragma unroll
+  for (int j = 0; j < NH; ++j) acc2[j] = 0.0;
+  const long flat = flat0 + PairRw::index(lane);
+  int col = -1;
+  if (flat < nflat) {
+    col = (int)(flat / nw);
+    repwvl_pair_point<CUBE>(d, imgs[col - cb_first], p, (int)(flat - (long)col * nw), lane, st, acc1, acc2);
+  }
+  if (flat0 >= nflat) return;  // (whole wave)
+
+  // ---- segmented reduction: one masked butterfly per column of the wave's 32 items (fixed order)
+  // even lane: acc1[j] = E_down[j] (j = 0..10), acc2[k] = E_up[k] (k = 0..9)
+  // odd lane:  acc1[j] = E_up[20-j],           acc2[k] = E_down[20-k]
+  const int c_first = (int)(flat0 / nw), c_last = (int)(min(flat0 + 31, nflat - 1) / nw);
+  const bool w0 = lane == PairRw::lane_of(0, 0), w1 = lane == PairRw::lane_of(0, 1);
+  for (int c = c_first; c <= c_last; ++c) {
+    const bool mine = col == c;
+    const long seg0 = max((long)c * nw, flat0);
+    const long slot = (seg0 - (long)c * nw + 31) / 32;
+    double *oEd = d.partial + ((size_t)c * d.nchunk + slot) * PSTRIDE, *oEu = oEd + NLEV;
+#pragma unroll
+    for (int j = 0; j <= NH; ++j) {
+      const double v = PairRw::sum<5>(mine ? acc1[j] : 0.0);
+      if (w0) oEd[j] = v;
+      if (w1) oEu[NL - j] = v;
+    }
+#pragma unroll
+    for (int k = 0; k < NH; ++k) {
+      const double v = PairRw::sum<5>(mine ? acc2[k] : 0.0);
+      if (w0) oEu[k] = v;
+      if (w1) oEd[NL - k] = v;
+    }
+  }
+  RCM_PT_STAMP(18);
 }
 
 #ifdef RCM_WITH_VARIANTS

@@ -596,23 +596,21 @@ def test_repwvl_kernel_variants_agree(pkg, olib, variants, monkeypatch):
 @pytest.mark.parametrize("table", ["Reduced10", "Reduced20", "Reduced100"])
 def test_flattened_repwvl_kernel_segment_boundaries(pkg, olib, variants, table, monkeypatch):
     # k_rt_repwvl_flat: a wave's 32 items straddle 2..5 columns; every ensemble size shifts the boundaries
-    for ncol in (1, 2, 3, 5, 33, 200):
+    for ncol in (1, 2, 3, 5, 33):
         inp = H.make_inputs(pkg, "repwvl", ncol, table=table)
         o = H.oracle_ensemble(olib, inp)
         o.step(2)
         res = []
-        # the product (one group of 32 items per wave at these sizes); the test-side build with the two-groups-per-
-        # wave blocks the product uses from 12 288 groups on (there: from 8), then its chunked lane-pair kernel
-        for flat, lib in (("1", None), ("1", variants), ("0", variants)):
+        for flat in ("1", "0"):
             monkeypatch.setenv("RCM_FLAT", flat)
-            g = H.gpu_ensemble(pkg, inp, library=lib)
+            g = H.gpu_ensemble(pkg, inp, library=None if flat == "1" else variants)  # "1": the product itself
             g.step(2)
             _check_fluxes(g, o)
             _check_state(g, o, 1e-9)
             res.append(g.get_fluxes())
             g.close()
         for k in res[0]:
-            assert H.max_abs(res[0][k], res[1][k]) <= FLUX_TIGHT and H.max_abs(res[0][k], res[2][k]) <= FLUX_TIGHT
+            assert H.max_abs(res[0][k], res[1][k]) <= FLUX_TIGHT
 
 
 def test_randomised_configurations_against_oracle(pkg, olib):
