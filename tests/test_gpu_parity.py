@@ -596,7 +596,7 @@ def test_repwvl_kernel_variants_agree(pkg, olib, variants, monkeypatch):
 @pytest.mark.parametrize("table", ["Reduced10", "Reduced20", "Reduced100"])
 def test_flattened_repwvl_kernel_segment_boundaries(pkg, olib, variants, table, monkeypatch):
     # k_rt_repwvl_flat: a wave's 32 items straddle 2..5 columns; every ensemble size shifts the boundaries
-    for ncol in (1, 2, 3, 5, 33):
+    for ncol in (1, 2, 3, 5, 33, 200):
         inp = H.make_inputs(pkg, "repwvl", ncol, table=table)
         o = H.oracle_ensemble(olib, inp)
         o.step(2)
