@@ -83,6 +83,9 @@ def run(ncases=120, seed=1, log=print, big=False):
         col = int(rng.integers(0, ncol))
         tg, to = g.get_tau(col), o.get_tau(col)
         e_tau = float(np.max(np.abs(tg - to) / np.maximum(np.abs(to), 1e-300)))
+        # ... and the optical depths as the production kernels form them (clamped to [-10, 1e7] there)
+        tp, tc = g.get_tau_production(col), np.clip(to, -10.0, 1e7)
+        e_tau = max(e_tau, float(np.max(np.abs(tp - tc) / np.maximum(np.abs(tc), 1e-300))))
         same_time = bool(np.array_equal(sg["time_h"], so["time_h"]))
         ok = e_flux <= FLUX_TOL and e_T <= T_TOL and e_tau <= TAU_RTOL and same_time
         bad += not ok
