@@ -238,13 +238,13 @@ void launch_rt_pair(rcm_ensemble *h, int blocks) {
   if (h->mode == rcm::MODE_LBL) {
     hipLaunchKernelGGL((rcm::k_rt_lbl_pair<CUBE>), dim3(blocks), dim3(64 * rcm::WPB), 0, h->stream, h->d);
   } else if (use_flat(h)) {
-    const int maxc = (rcm::WPB * 32 - 1) / h->d.n_wvl + 2;  // columns the 128 consecutive items of a block can touch
-    const size_t lds = (size_t)maxc * sizeof(rcm::RepwvlPairLds) + (size_t)rcm::WPB * (rcm::NH + 1) * 64 * sizeof(double);
+    const int maxc = (rcm::FWPB * 32 - 1) / h->d.n_wvl + 2;  // columns the consecutive items of a block can touch
+    const size_t lds = (size_t)maxc * sizeof(rcm::RepwvlPairLds) + (size_t)rcm::FWPB * (rcm::NH + 1) * 64 * sizeof(double);
     const long waves = ((long)h->ncol * h->d.n_wvl + 31) / 32;
     const auto kern = rcm::k_rt_repwvl_flat<CUBE>;
     if (lds > 48 * 1024)
       (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL(kern, dim3((unsigned)((waves + rcm::WPB - 1) / rcm::WPB)), dim3(64 * rcm::WPB), lds, h->stream,
+    hipLaunchKernelGGL(kern, dim3((unsigned)((waves + rcm::FWPB - 1) / rcm::FWPB)), dim3(64 * rcm::FWPB), lds, h->stream,
                        h->d, maxc);
   } else {
     hipLaunchKernelGGL((rcm::k_rt_repwvl_pair<CUBE>), dim3(blocks), dim3(64 * rcm::WPB), 0, h->stream, h->d);
@@ -353,10 +353,13 @@ int launch_fused_steps(rcm_ensemble *h, int lpc, int nsteps) {
 
 #endif  // RCM_WITH_VARIANTS
 
-int launch_step(rcm_ensemble *h) {
+// One iteration.  have_pre: the previous k_post of this rcm_step call already did this iteration's adjustment and
+// feedback; next_pre: this iteration's k_post goes on with the next one's.
+int launch_step(rcm_ensemble *h, bool have_pre, bool next_pre) {
   Dev &d = h->d;
   const int first = (h->step_index == 0) ? 1 : 0;
-  hipLaunchKernelGGL(rcm::k_pre, dim3((h->ncol + rcm::WPB - 1) / rcm::WPB), dim3(64 * rcm::WPB), 0, h->stream, d, first);
+  if (!have_pre)
+    hipLaunchKernelGGL(rcm::k_pre, dim3((h->ncol + rcm::WPB - 1) / rcm::WPB), dim3(64 * rcm::WPB), 0, h->stream, d, first);
   const int blocks = (int)(((long)h->ncol * d.nchunk + rcm::WPB - 1) / rcm::WPB);
   hipEvent_t e1 = nullptr;
   if (int rc = timing_begin(h, &e1)) return rc;
@@ -372,7 +375,7 @@ int launch_step(rcm_ensemble *h) {
   }
   int post_waves = dp.nchunk / 16;  // waves per column in k_post: one per 16 chunk partials, 1..16
   post_waves = post_waves < 1 ? 1 : (post_waves > 16 ? 16 : post_waves);
-  hipLaunchKernelGGL(rcm::k_post, dim3(h->ncol), dim3(64 * post_waves), 0, h->stream, dp);
+  hipLaunchKernelGGL(rcm::k_post, dim3(h->ncol), dim3(64 * post_waves), 0, h->stream, dp, next_pre ? 1 : 0);
   HIPCK(hipGetLastError());
   ++h->step_index;
   return RCM_OK;
@@ -791,7 +794,7 @@ int rcm_step(rcm_ensemble *h, int nsteps) {
   if (!h->d.partial)
     if (int rc = ensure_partials(h)) return rc;
   for (int i = 0; i < nsteps; ++i)
-    if (int rc = launch_step(h)) return rc;
+    if (int rc = launch_step(h, i > 0, i + 1 < nsteps)) return rc;
   return RCM_OK;
 }
 

@@ -929,11 +929,15 @@ __global__ __launch_bounds__(64 * WPB, RCM_PAIR_LB) void k_rt_repwvl_pair(Dev d)
 // records never collide and the slots a column never uses stay zero (the buffer is zeroed once).
 // d.nchunk = number of slots.
 // ---------------------------------------------------------------------------------------------
+#ifndef RCM_FLAT_WPB
+#define RCM_FLAT_WPB 4  // waves per block of k_rt_repwvl_flat (they share the column images)
+#endif
+constexpr int FWPB = RCM_FLAT_WPB;
 #ifndef RCM_FLAT_LB
 #define RCM_FLAT_LB 4  // waves per SIMD k_rt_repwvl_flat is register-allocated for
 #endif
 template <int CUBE>
-__global__ __launch_bounds__(64 * WPB, RCM_FLAT_LB) void k_rt_repwvl_flat(Dev d, int maxc) {
+__global__ __launch_bounds__(64 * FWPB, RCM_FLAT_LB) void k_rt_repwvl_flat(Dev d, int maxc) {
   extern __shared__ __align__(16) unsigned char s_dyn[];
   const int lane = threadIdx.x & 63;
   const int wib = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -943,15 +947,15 @@ __global__ __launch_bounds__(64 * WPB, RCM_FLAT_LB) void k_rt_repwvl_flat(Dev d,
   const int p = PairRw::parity(lane);
   const long nw = d.n_wvl;
   const long nflat = (long)d.ncol * nw;
-  const long blk0 = (long)blockIdx.x * (WPB * 32);
+  const long blk0 = (long)blockIdx.x * (FWPB * 32);
   const long flat0 = blk0 + wib * 32;
   int cb_first = 0, ncb = 0;  // first column and number of columns the block touches
   if (blk0 < nflat) {
     cb_first = (int)(blk0 / nw);
-    ncb = (int)(min(blk0 + WPB * 32 - 1, nflat - 1) / nw) - cb_first + 1;
+    ncb = (int)(min(blk0 + FWPB * 32 - 1, nflat - 1) / nw) - cb_first + 1;
   }
   RCM_PT_STAMP(16);
-  for (int sl = wib; sl < ncb; sl += WPB) repwvl_pair_image(d, cb_first + sl, lane, imgs[sl]);
+  for (int sl = wib; sl < ncb; sl += FWPB) repwvl_pair_image(d, cb_first + sl, lane, imgs[sl]);
   __syncthreads();
   RCM_PT_STAMP(17);
 
@@ -1366,7 +1370,11 @@ __global__ __launch_bounds__(1024) void k_reduce_partials(const double *partial,
 // q, q+P, q+2P, .. in that order, the P sums are combined in wave order (deterministic for a given
 // chunking), then lane 0 runs the tail of radiative_transfer (main.cpp:337-341), calculate_timestep
 // (:156-162), thermodynamics (:164-176) and the time accumulation (:581).
-__global__ __launch_bounds__(1024) void k_post(Dev d) {
+// With next_pre != 0 the block goes on with the START of the next iteration for its column -- convective
+// adjustment, equilibrium residual, water-vapour feedback: k_pre's work with first == 0 -- so that inside
+// rcm_step(h, n) only the first iteration launches k_pre (two launches per iteration instead of three; the last
+// k_post of a call runs with next_pre == 0 and leaves the state as main.cpp:583 does, for the getters).
+__global__ __launch_bounds__(1024) void k_post(Dev d, int next_pre) {
   __shared__ double s_part[16][PSTRIDE];
   __shared__ double s_E[PSTRIDE];
   const int c = blockIdx.x;
@@ -1405,21 +1413,67 @@ __global__ __launch_bounds__(1024) void k_post(Dev d) {
     s_dE[l] = dEl;
   }
   __syncthreads();
-  if (l >= NL) return;
-  double mx = s_dE[0];
+  if (threadIdx.x >= 64) return;  // the rest is the first wave's: lane l = layer l (no block barrier below)
+  const bool on = l < NL;
+  const size_t at = (size_t)c * NL + (on ? l : 0);
+  double Tn = 0.0, conv = 1.0;
+  if (on) {
+    double mx = s_dE[0];
 #pragma unroll
-  for (int i = 1; i < NL; ++i) mx = (mx < s_dE[i]) ? s_dE[i] : mx;  // signed max_element, main.cpp:157
-  const double heat_cap = 1004.0 * d.dp * 100.0;               // c_air * dp * 100, main.cpp:157,169
-  double dt = 5.0 / mx * heat_cap / 9.80665;                   // max_dT = 5 (float), main.cpp:82
-  if (dt > 3600 * 12) dt = 3600 * 12;                          // main.cpp:158-160
-  const double Tn = d.T[(size_t)c * NL + l] + dEl * dt * 9.80665 / heat_cap;  // main.cpp:169
-  d.T[(size_t)c * NL + l] = Tn;
-  d.dE[(size_t)c * NL + l] = dEl;
-  if (l == NL - 1) d.Tsfc[c] = Tn * d.conv[NL - 1];            // main.cpp:173
-  if (l == 0) {
-    d.dt[c] = dt;
-    d.time_h[c] += (float)dt / 3600;                           // main.cpp:581
+    for (int i = 1; i < NL; ++i) mx = (mx < s_dE[i]) ? s_dE[i] : mx;  // signed max_element, main.cpp:157
+    const double heat_cap = 1004.0 * d.dp * 100.0;               // c_air * dp * 100, main.cpp:157,169
+    double dt = 5.0 / mx * heat_cap / 9.80665;                   // max_dT = 5 (float), main.cpp:82
+    if (dt > 3600 * 12) dt = 3600 * 12;                          // main.cpp:158-160
+    Tn = d.T[at] + dEl * dt * 9.80665 / heat_cap;                // main.cpp:169
+    conv = d.conv[l];
+    d.dE[at] = dEl;
+    if (l == NL - 1) d.Tsfc[c] = Tn * conv;                      // main.cpp:173
+    if (l == 0) {
+      d.dt[c] = dt;
+      d.time_h[c] += (float)dt / 3600;                           // main.cpp:581
+    }
+    if (!next_pre) d.T[at] = Tn;
   }
+  if (!next_pre) return;
+  // ---- start of the next iteration (main.cpp:536-572; k_pre with first == 0), one wave: its LDS operations
+  //      execute in program order
+  __shared__ double s_th[NL], s_sorted[NL];
+  double th = 0.0;
+  if (on) {
+    th = Tn * conv;                      // t_to_theta, main.cpp:123-129
+    s_th[l] = th;
+    s_sorted[l] = __builtin_nan("");     // a NaN among the inputs leaves ranks unassigned: the column stays NaN
+  }
+  __builtin_amdgcn_wave_barrier();
+  if (on) {
+    int rank = 0;
+    for (int i = 0; i < NL; ++i) {
+      const double ti = s_th[i];
+      rank += (ti > th) || (ti == th && i < l);
+    }
+    s_sorted[rank] = th;                 // sort(theta, greater), main.cpp:538
+  }
+  __builtin_amdgcn_wave_barrier();
+  double r = 0.0;
+  if (on) {
+    const double T = s_sorted[l] / conv;  // theta_to_t, main.cpp:131-139
+    d.T[at] = T;
+    r = fabs(T - d.Tprev[at]);
+    d.Tprev[at] = T;
+    d.Ttau[at] = T;
+    const double vmr = d.rel_hum[at] * magnus_dev(T) / d.player[l];  // main.cpp:285-286
+    double *gas = d.gas + (size_t)c * d.ngas * NL;
+    if (d.mode == MODE_REPWVL)
+      gas[0 * NL + l] = vmr;                    // H2O is read_tau's first species
+    else
+      gas[1 * NL + l] = vmr / d.h2o_ref[l];     // lbl: tau_H2O is linear in the mixing ratio
+  }
+#pragma unroll
+  for (int off = 16; off >= 1; off >>= 1) {  // lanes 0..31 cover the 20 layers; a NaN layer makes the residual NaN
+    const double o = __shfl_xor(r, off, 64);
+    r = (o > r || o != o) ? o : r;
+  }
+  if (l == 0) d.resid[c] = r;
 }
 
 // output_conv view of one column (main.cpp:536-546) into scratch: adjusted T, sorted theta.

@@ -21,7 +21,8 @@ libs = {"product": pkg.lib()}
 for so in sorted(glob.glob(os.path.join(ROOT, "our_first_climate_model_amd", "variants", "librcm_hip_*.so"))):
     libs[os.path.basename(so)[len("librcm_hip_"):-3]] = pkg.load_library(so)
 inp = H.make_inputs(pkg, "repwvl", ncol, table="Reduced100")
-cases = [("flat", 0, None), ("fused16", 1, "16"), ("fused32", 1, "32"), ("fused8", 1, "8")]
+# the fused kernel exists only in builds with -DRCM_WITH_VARIANTS (add -DRCM_LPC_ENV to force its lane pairs per column)
+cases = [("flat", 0, None)] + ([("fused16", 1, "16"), ("fused32", 1, "32")] if os.environ.get("AB_FUSED") else [])
 ens = {}
 for name, L in libs.items():
     for cname, fusion, lpc in cases:
