@@ -82,6 +82,7 @@ struct Dev {
   // (main.cpp:341), grey cloud layer index (-1: none) and optical depth (main.cpp:266-274)
   const double *solar_irr, *cloud_tau;
   const int *cloud_layer;
+  int *colcnt;              // per column: groups of the flattened repwvl kernel that have delivered their partial record
   unsigned long long *dbg;  // phase time stamps of sampled waves (builds with -DRCM_DBG_STAMPS only; else null)
   double *resid;  // equilibrium residual per column: max_l |change of the ADJUSTED profile| between the
                   // last two iterations [K] (1e300 until two iterations have run)
@@ -915,6 +916,82 @@ __global__ __launch_bounds__(64 * WPB, RCM_PAIR_LB) void k_rt_repwvl_pair(Dev d)
 }
 
 // ---------------------------------------------------------------------------------------------
+// End of an iteration for column c, executed by ONE wave (lane l = layer l) once the column's fluxes E = {E_down[21],
+// E_up[21]} stand in LDS: tail of radiative_transfer (main.cpp:337-341), calculate_timestep (:156-162), thermodynamics
+// (:164-176), time (:581).  With next_pre the wave goes on with the START of the next iteration -- convective
+// adjustment, equilibrium residual, water-vapour feedback (main.cpp:536-572; k_pre's work with first == 0).
+// scr: 3*NL doubles of LDS scratch owned by the wave.  A wave's LDS operations execute in program order.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ void post_column(const Dev &d, int c, int l, const double *E, double *scr, int next_pre) {
+  const double *Ed = E, *Eu = E + NLEV;
+  double *s_dE = scr, *s_th = scr + NL, *s_sorted = scr + 2 * NL;
+  const bool on = l < NL;
+  const size_t at = (size_t)c * NL + (on ? l : 0);
+  double dEl = 0.0;
+  if (on) {
+    dEl = Ed[l] - Ed[l + 1] + Eu[l + 1] - Eu[l];                     // main.cpp:338
+    if (l == NL - 1) dEl += d.solar_irr[c] + Ed[NL] - Eu[NL];         // main.cpp:341
+    s_dE[l] = dEl;
+  }
+  __builtin_amdgcn_wave_barrier();
+  double Tn = 0.0, conv = 1.0;
+  if (on) {
+    double mx = s_dE[0];
+#pragma unroll
+    for (int i = 1; i < NL; ++i) mx = (mx < s_dE[i]) ? s_dE[i] : mx;  // signed max_element, main.cpp:157
+    const double heat_cap = 1004.0 * d.dp * 100.0;               // c_air * dp * 100, main.cpp:157,169
+    double dt = 5.0 / mx * heat_cap / 9.80665;                   // max_dT = 5 (float), main.cpp:82
+    if (dt > 3600 * 12) dt = 3600 * 12;                          // main.cpp:158-160
+    Tn = d.T[at] + dEl * dt * 9.80665 / heat_cap;                // main.cpp:169
+    conv = d.conv[l];
+    d.dE[at] = dEl;
+    if (l == NL - 1) d.Tsfc[c] = Tn * conv;                      // main.cpp:173
+    if (l == 0) {
+      d.dt[c] = dt;
+      d.time_h[c] += (float)dt / 3600;                           // main.cpp:581
+    }
+    if (!next_pre) d.T[at] = Tn;
+  }
+  if (!next_pre) return;
+  double th = 0.0;
+  if (on) {
+    th = Tn * conv;                      // t_to_theta, main.cpp:123-129
+    s_th[l] = th;
+    s_sorted[l] = __builtin_nan("");     // a NaN among the inputs leaves ranks unassigned: the column stays NaN
+  }
+  __builtin_amdgcn_wave_barrier();
+  if (on) {
+    int rank = 0;
+    for (int i = 0; i < NL; ++i) {
+      const double ti = s_th[i];
+      rank += (ti > th) || (ti == th && i < l);
+    }
+    s_sorted[rank] = th;                 // sort(theta, greater), main.cpp:538
+  }
+  __builtin_amdgcn_wave_barrier();
+  double r = 0.0;
+  if (on) {
+    const double T = s_sorted[l] / conv;  // theta_to_t, main.cpp:131-139
+    d.T[at] = T;
+    r = fabs(T - d.Tprev[at]);
+    d.Tprev[at] = T;
+    d.Ttau[at] = T;
+    const double vmr = d.rel_hum[at] * magnus_dev(T) / d.player[l];  // main.cpp:285-286
+    double *gas = d.gas + (size_t)c * d.ngas * NL;
+    if (d.mode == MODE_REPWVL)
+      gas[0 * NL + l] = vmr;                    // H2O is read_tau's first species
+    else
+      gas[1 * NL + l] = vmr / d.h2o_ref[l];     // lbl: tau_H2O is linear in the mixing ratio
+  }
+#pragma unroll
+  for (int off = 16; off >= 1; off >>= 1) {  // lanes 0..31 cover the 20 layers; a NaN layer makes the residual NaN
+    const double o = __shfl_xor(r, off, 64);
+    r = (o > r || o != o) ? o : r;
+  }
+  if (l == 0) d.resid[c] = r;
+}
+
+// ---------------------------------------------------------------------------------------------
 // The same, with the (column, wavelength) pairs FLATTENED over the lane pairs: wave i takes the 32
 // consecutive items 32i..32i+31 of the column-major list, whichever columns they belong to.  100 wavelengths
 // fill 100/128 of the lane pairs in the chunked kernel, 10 wavelengths 10/32; here every pass is full, and the
@@ -937,7 +1014,7 @@ constexpr int FWPB = RCM_FLAT_WPB;
 #define RCM_FLAT_LB 4  // waves per SIMD k_rt_repwvl_flat is register-allocated for
 #endif
 template <int CUBE>
-__global__ __launch_bounds__(64 * FWPB, RCM_FLAT_LB) void k_rt_repwvl_flat(Dev d, int maxc) {
+__global__ __launch_bounds__(64 * FWPB, RCM_FLAT_LB) void k_rt_repwvl_flat(Dev d, int maxc, int post_mode) {
   extern __shared__ __align__(16) unsigned char s_dyn[];
   const int lane = threadIdx.x & 63;
   const int wib = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -993,6 +1070,35 @@ __global__ __launch_bounds__(64 * FWPB, RCM_FLAT_LB) void k_rt_repwvl_flat(Dev d
       const double v = PairRw::sum<5>(mine ? acc2[k] : 0.0);
       if (w0) oEu[k] = v;
       if (w1) oEd[NL - k] = v;
+    }
+    if (post_mode) {
+      // ---- the END OF THE ITERATION for column c, by whichever wave delivers the column's last record: no k_post
+      // launch (post_mode 2: and no k_pre launch for the next iteration either).  Release/acquire through an
+      // agent-scope counter: the records of the other waves may come from other CUs and other XCDs.
+      __threadfence();
+      int last = 0;
+      if (lane == 0) {
+        const int expected = (int)((((long)c + 1) * nw - 1) / 32 - ((long)c * nw) / 32) + 1;  // groups that overlap column c
+        last = atomicAdd(&d.colcnt[c], 1) + 1 == expected;
+      }
+      if (__builtin_amdgcn_readfirstlane(last)) {  // wave-uniform
+        __threadfence();
+        if (lane == 0) d.colcnt[c] = 0;  // ready for the next launch
+        double *E = &st[0][0], *scr = &st[1][0];  // the staging columns are free after the angle loop
+        if (lane < PSTRIDE) {
+          const double *pr = d.partial + (size_t)c * d.nchunk * PSTRIDE + lane;
+          double acc = 0.0;
+          for (int k = 0; k < d.nchunk; ++k) acc += pr[(size_t)k * PSTRIDE];  // slot order: deterministic
+          E[lane] = acc;
+          if (lane < NLEV)
+            d.E_down[(size_t)c * NLEV + lane] = acc;
+          else
+            d.E_up[(size_t)c * NLEV + (lane - NLEV)] = acc;
+        }
+        __builtin_amdgcn_wave_barrier();
+        post_column(d, c, lane, E, scr, post_mode == 2);
+        __builtin_amdgcn_wave_barrier();
+      }
     }
   }
   RCM_PT_STAMP(18);
@@ -1402,78 +1508,9 @@ __global__ __launch_bounds__(1024) void k_post(Dev d, int next_pre) {
       d.E_up[(size_t)c * NLEV + (j - NLEV)] = acc;
   }
   __syncthreads();
-  // dE, time step and temperature update: lane l of the first wave = layer l
-  __shared__ double s_dE[NL];
-  const int l = threadIdx.x;
-  const double *Ed = s_E, *Eu = s_E + NLEV;
-  double dEl = 0.0;
-  if (l < NL) {
-    dEl = Ed[l] - Ed[l + 1] + Eu[l + 1] - Eu[l];                    // main.cpp:338
-    if (l == NL - 1) dEl += d.solar_irr[c] + Ed[NL] - Eu[NL];        // main.cpp:341
-    s_dE[l] = dEl;
-  }
-  __syncthreads();
   if (threadIdx.x >= 64) return;  // the rest is the first wave's: lane l = layer l (no block barrier below)
-  const bool on = l < NL;
-  const size_t at = (size_t)c * NL + (on ? l : 0);
-  double Tn = 0.0, conv = 1.0;
-  if (on) {
-    double mx = s_dE[0];
-#pragma unroll
-    for (int i = 1; i < NL; ++i) mx = (mx < s_dE[i]) ? s_dE[i] : mx;  // signed max_element, main.cpp:157
-    const double heat_cap = 1004.0 * d.dp * 100.0;               // c_air * dp * 100, main.cpp:157,169
-    double dt = 5.0 / mx * heat_cap / 9.80665;                   // max_dT = 5 (float), main.cpp:82
-    if (dt > 3600 * 12) dt = 3600 * 12;                          // main.cpp:158-160
-    Tn = d.T[at] + dEl * dt * 9.80665 / heat_cap;                // main.cpp:169
-    conv = d.conv[l];
-    d.dE[at] = dEl;
-    if (l == NL - 1) d.Tsfc[c] = Tn * conv;                      // main.cpp:173
-    if (l == 0) {
-      d.dt[c] = dt;
-      d.time_h[c] += (float)dt / 3600;                           // main.cpp:581
-    }
-    if (!next_pre) d.T[at] = Tn;
-  }
-  if (!next_pre) return;
-  // ---- start of the next iteration (main.cpp:536-572; k_pre with first == 0), one wave: its LDS operations
-  //      execute in program order
-  __shared__ double s_th[NL], s_sorted[NL];
-  double th = 0.0;
-  if (on) {
-    th = Tn * conv;                      // t_to_theta, main.cpp:123-129
-    s_th[l] = th;
-    s_sorted[l] = __builtin_nan("");     // a NaN among the inputs leaves ranks unassigned: the column stays NaN
-  }
-  __builtin_amdgcn_wave_barrier();
-  if (on) {
-    int rank = 0;
-    for (int i = 0; i < NL; ++i) {
-      const double ti = s_th[i];
-      rank += (ti > th) || (ti == th && i < l);
-    }
-    s_sorted[rank] = th;                 // sort(theta, greater), main.cpp:538
-  }
-  __builtin_amdgcn_wave_barrier();
-  double r = 0.0;
-  if (on) {
-    const double T = s_sorted[l] / conv;  // theta_to_t, main.cpp:131-139
-    d.T[at] = T;
-    r = fabs(T - d.Tprev[at]);
-    d.Tprev[at] = T;
-    d.Ttau[at] = T;
-    const double vmr = d.rel_hum[at] * magnus_dev(T) / d.player[l];  // main.cpp:285-286
-    double *gas = d.gas + (size_t)c * d.ngas * NL;
-    if (d.mode == MODE_REPWVL)
-      gas[0 * NL + l] = vmr;                    // H2O is read_tau's first species
-    else
-      gas[1 * NL + l] = vmr / d.h2o_ref[l];     // lbl: tau_H2O is linear in the mixing ratio
-  }
-#pragma unroll
-  for (int off = 16; off >= 1; off >>= 1) {  // lanes 0..31 cover the 20 layers; a NaN layer makes the residual NaN
-    const double o = __shfl_xor(r, off, 64);
-    r = (o > r || o != o) ? o : r;
-  }
-  if (l == 0) d.resid[c] = r;
+  __shared__ double s_scr[3 * NL];
+  post_column(d, c, threadIdx.x, s_E, s_scr, next_pre);
 }
 
 // output_conv view of one column (main.cpp:536-546) into scratch: adjusted T, sorted theta.
