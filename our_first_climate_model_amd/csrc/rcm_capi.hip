@@ -234,7 +234,7 @@ int ensure_partials(rcm_ensemble *h) {
 
 // The production kernels: lane pairs, cube/root-pair angle chains (CUBE = 1), own exp and narrow-band Planck.
 template <int CUBE>
-void launch_rt_pair(rcm_ensemble *h, int blocks, int post_mode) {
+void launch_rt_pair(rcm_ensemble *h, int blocks) {
   if (h->mode == rcm::MODE_LBL) {
     hipLaunchKernelGGL((rcm::k_rt_lbl_pair<CUBE>), dim3(blocks), dim3(64 * rcm::WPB), 0, h->stream, h->d);
   } else if (use_flat(h)) {
@@ -245,7 +245,7 @@ void launch_rt_pair(rcm_ensemble *h, int blocks, int post_mode) {
     if (lds > 48 * 1024)
       (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipLaunchKernelGGL(kern, dim3((unsigned)((waves + rcm::FWPB - 1) / rcm::FWPB)), dim3(64 * rcm::FWPB), lds, h->stream,
-                       h->d, maxc, post_mode);
+                       h->d, maxc);
   } else {
     hipLaunchKernelGGL((rcm::k_rt_repwvl_pair<CUBE>), dim3(blocks), dim3(64 * rcm::WPB), 0, h->stream, h->d);
   }
@@ -268,7 +268,7 @@ void launch_rt_variant(rcm_ensemble *h, int blocks) {
 }
 #endif
 
-void launch_rt(rcm_ensemble *h, int blocks, int post_mode) {
+void launch_rt(rcm_ensemble *h, int blocks) {
 #ifdef RCM_WITH_VARIANTS
   const bool production = h->exp_variant == 1 && h->pair && (h->mode != rcm::MODE_LBL || h->planck_fast);
   if (!production) {
@@ -283,11 +283,11 @@ void launch_rt(rcm_ensemble *h, int blocks, int post_mode) {
     return;
   }
   if (!h->cube) {
-    launch_rt_pair<0>(h, blocks, post_mode);
+    launch_rt_pair<0>(h, blocks);
     return;
   }
 #endif
-  launch_rt_pair<1>(h, blocks, post_mode);
+  launch_rt_pair<1>(h, blocks);
 }
 
 int timing_begin(rcm_ensemble *h, hipEvent_t *e1) {
@@ -363,16 +363,8 @@ int launch_step(rcm_ensemble *h, bool have_pre, bool next_pre) {
   const int blocks = (int)(((long)h->ncol * d.nchunk + rcm::WPB - 1) / rcm::WPB);
   hipEvent_t e1 = nullptr;
   if (int rc = timing_begin(h, &e1)) return rc;
-  // the flattened repwvl kernel ends the iteration itself (the wave that delivers a column's last record runs k_post's
-  // work for it, and with next_pre k_pre's for the next iteration): one launch per iteration
-  const int post_mode = use_flat(h) ? (next_pre ? 2 : 1) : 0;
-  launch_rt(h, blocks, post_mode);
+  launch_rt(h, blocks);
   if (e1) HIPCK(hipEventRecord(e1, h->stream));
-  if (post_mode) {
-    HIPCK(hipGetLastError());
-    ++h->step_index;
-    return RCM_OK;
-  }
   Dev dp = d;  // what k_post sums: the chunk records, or their slice sums
   if (h->slice_buf) {
     const int len = (d.nchunk + kPostSlices - 1) / kPostSlices;
@@ -466,7 +458,6 @@ int rcm_create(int ncol, int nlayer, int nangle, int device, void *stream, rcm_e
   rc = rc ? rc : dev_alloc(h, (double **)&d.cloud_tau, (size_t)ncol);
   rc = rc ? rc : dev_alloc(h, (int **)&d.cloud_layer, (size_t)ncol);
   rc = rc ? rc : dev_alloc(h, &d.resid, (size_t)ncol);
-  rc = rc ? rc : dev_alloc(h, &d.colcnt, (size_t)ncol);
   rc = rc ? rc : dev_alloc(h, &d.Tprev, nT);
   rc = rc ? rc : dev_alloc(h, (double **)&d.player, (size_t)NL);
   rc = rc ? rc : dev_alloc(h, (double **)&d.conv, (size_t)NL);
@@ -516,7 +507,6 @@ int rcm_create(int ncol, int nlayer, int nangle, int device, void *stream, rcm_e
   if (me == hipSuccess) me = hipMemsetAsync(d.E_up, 0, nE * sizeof(double), h->stream);
   if (me == hipSuccess) me = hipMemsetAsync(d.dE, 0, nT * sizeof(double), h->stream);
   if (me == hipSuccess) me = hipMemsetAsync(d.resid, 0, ncol * sizeof(double), h->stream);
-  if (me == hipSuccess) me = hipMemsetAsync(d.colcnt, 0, ncol * sizeof(int), h->stream);
   if (me == hipSuccess) me = hipMemsetAsync(d.Tprev, 0, nT * sizeof(double), h->stream);
   if (me == hipSuccess) me = hipStreamSynchronize(h->stream);
   if (me != hipSuccess) return bail(fail(RCM_ERR_HIP, std::string("rcm_create: ") + hipGetErrorString(me)));

@@ -82,7 +82,6 @@ struct Dev {
   // (main.cpp:341), grey cloud layer index (-1: none) and optical depth (main.cpp:266-274)
   const double *solar_irr, *cloud_tau;
   const int *cloud_layer;
-  int *colcnt;              // per column: groups of the flattened repwvl kernel that have delivered their partial record
   unsigned long long *dbg;  // phase time stamps of sampled waves (builds with -DRCM_DBG_STAMPS only; else null)
   double *resid;  // equilibrium residual per column: max_l |change of the ADJUSTED profile| between the
                   // last two iterations [K] (1e300 until two iterations have run)
@@ -915,11 +914,6 @@ __global__ __launch_bounds__(64 * WPB, RCM_PAIR_LB) void k_rt_repwvl_pair(Dev d)
   store_pair_partial<PairRw>(d, col, chunk, lane, valid, acc1, acc2);
 }
 
-// A store performed at agent scope (past the XCDs' L2s), relaxed: see k_rt_repwvl_flat.
-__device__ __forceinline__ void store_agent(double *p, double v) {
-  __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-
 // ---------------------------------------------------------------------------------------------
 // End of an iteration for column c, executed by ONE wave (lane l = layer l) once the column's fluxes E = {E_down[21],
 // E_up[21]} stand in LDS: tail of radiative_transfer (main.cpp:337-341), calculate_timestep (:156-162), thermodynamics
@@ -1019,7 +1013,7 @@ constexpr int FWPB = RCM_FLAT_WPB;
 #define RCM_FLAT_LB 4  // waves per SIMD k_rt_repwvl_flat is register-allocated for
 #endif
 template <int CUBE>
-__global__ __launch_bounds__(64 * FWPB, RCM_FLAT_LB) void k_rt_repwvl_flat(Dev d, int maxc, int post_mode) {
+__global__ __launch_bounds__(64 * FWPB, RCM_FLAT_LB) void k_rt_repwvl_flat(Dev d, int maxc) {
   extern __shared__ __align__(16) unsigned char s_dyn[];
   const int lane = threadIdx.x & 63;
   const int wib = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -1067,47 +1061,14 @@ __global__ __launch_bounds__(64 * FWPB, RCM_FLAT_LB) void k_rt_repwvl_flat(Dev d
 #pragma unroll
     for (int j = 0; j <= NH; ++j) {
       const double v = PairRw::sum<5>(mine ? acc1[j] : 0.0);
-      if (w0) store_agent(oEd + j, v);
-      if (w1) store_agent(oEu + (NL - j), v);
+      if (w0) oEd[j] = v;
+      if (w1) oEu[NL - j] = v;
     }
 #pragma unroll
     for (int k = 0; k < NH; ++k) {
       const double v = PairRw::sum<5>(mine ? acc2[k] : 0.0);
-      if (w0) store_agent(oEu + k, v);
-      if (w1) store_agent(oEd + (NL - k), v);
-    }
-    if (post_mode) {
-      // ---- the END OF THE ITERATION for column c, by whichever wave delivers the column's last record: no k_post
-      // launch (post_mode 2: and no k_pre launch for the next iteration either).  The records of the other waves
-      // come from other CUs and other XCDs (whose L2s are not coherent with each other): they are written and read
-      // with agent-scope accesses (performed at the coherence point, past the L2s), the writer waits for its stores
-      // to be acknowledged (s_waitcnt vmcnt(0)) before it bumps the column's agent-scope counter.  No fence: a
-      // release fence writes the whole L2 back and an acquire fence invalidates it (measured: 1.77 ms per step
-      // instead of 0.40 with __threadfence() here).
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      int last = 0;
-      if (lane == 0) {
-        const int expected = (int)((((long)c + 1) * nw - 1) / 32 - ((long)c * nw) / 32) + 1;  // groups that overlap column c
-        last = __hip_atomic_fetch_add(&d.colcnt[c], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1 == expected;
-      }
-      if (__builtin_amdgcn_readfirstlane(last)) {  // wave-uniform
-        if (lane == 0) __hip_atomic_store(&d.colcnt[c], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // for the next launch
-        double *E = &st[0][0], *scr = &st[1][0];  // the staging columns are free after the angle loop
-        if (lane < PSTRIDE) {
-          const double *pr = d.partial + (size_t)c * d.nchunk * PSTRIDE + lane;
-          double acc = 0.0;
-          for (int k = 0; k < d.nchunk; ++k)  // slot order: deterministic
-            acc += __hip_atomic_load(pr + (size_t)k * PSTRIDE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          E[lane] = acc;
-          if (lane < NLEV)
-            d.E_down[(size_t)c * NLEV + lane] = acc;
-          else
-            d.E_up[(size_t)c * NLEV + (lane - NLEV)] = acc;
-        }
-        __builtin_amdgcn_wave_barrier();
-        post_column(d, c, lane, E, scr, post_mode == 2);
-        __builtin_amdgcn_wave_barrier();
-      }
+      if (w0) oEu[k] = v;
+      if (w1) oEd[NL - k] = v;
     }
   }
   RCM_PT_STAMP(18);
