@@ -921,7 +921,29 @@ __global__ __launch_bounds__(64 * WPB, RCM_PAIR_LB) void k_rt_repwvl_pair(Dev d)
 // adjustment, equilibrium residual, water-vapour feedback (main.cpp:536-572; k_pre's work with first == 0).
 // scr: 3*NL doubles of LDS scratch owned by the wave.  A wave's LDS operations execute in program order.
 // ---------------------------------------------------------------------------------------------
-__device__ __forceinline__ void post_column(const Dev &d, int c, int l, const double *E, double *scr, int next_pre) {
+struct PostIn {  // what post_column reads from HBM for (column c, layer l): loaded by the caller up front, so that
+  double T, conv, solar, Tprev, rel_hum, player, h2o_ref;  // the latencies overlap the sum of the partial records
+};
+
+__device__ __forceinline__ PostIn post_load(const Dev &d, int c, int l, int next_pre) {
+  PostIn in{};
+  if (l < NL) {
+    const size_t at = (size_t)c * NL + l;
+    in.T = d.T[at];
+    in.conv = d.conv[l];
+    in.solar = d.solar_irr[c];
+    if (next_pre) {
+      in.Tprev = d.Tprev[at];
+      in.rel_hum = d.rel_hum[at];
+      in.player = d.player[l];
+      in.h2o_ref = d.mode == MODE_LBL ? d.h2o_ref[l] : 1.0;
+    }
+  }
+  return in;
+}
+
+__device__ __forceinline__ void post_column(const Dev &d, int c, int l, const PostIn &in, const double *E, double *scr,
+                                            int next_pre) {
   const double *Ed = E, *Eu = E + NLEV;
   double *s_dE = scr, *s_th = scr + NL, *s_sorted = scr + 2 * NL;
   const bool on = l < NL;
@@ -929,11 +951,12 @@ __device__ __forceinline__ void post_column(const Dev &d, int c, int l, const do
   double dEl = 0.0;
   if (on) {
     dEl = Ed[l] - Ed[l + 1] + Eu[l + 1] - Eu[l];                     // main.cpp:338
-    if (l == NL - 1) dEl += d.solar_irr[c] + Ed[NL] - Eu[NL];         // main.cpp:341
+    if (l == NL - 1) dEl += in.solar + Ed[NL] - Eu[NL];               // main.cpp:341
     s_dE[l] = dEl;
   }
   __builtin_amdgcn_wave_barrier();
-  double Tn = 0.0, conv = 1.0;
+  double Tn = 0.0;
+  const double conv = in.conv;
   if (on) {
     double mx = s_dE[0];
 #pragma unroll
@@ -941,8 +964,7 @@ __device__ __forceinline__ void post_column(const Dev &d, int c, int l, const do
     const double heat_cap = 1004.0 * d.dp * 100.0;               // c_air * dp * 100, main.cpp:157,169
     double dt = 5.0 / mx * heat_cap / 9.80665;                   // max_dT = 5 (float), main.cpp:82
     if (dt > 3600 * 12) dt = 3600 * 12;                          // main.cpp:158-160
-    Tn = d.T[at] + dEl * dt * 9.80665 / heat_cap;                // main.cpp:169
-    conv = d.conv[l];
+    Tn = in.T + dEl * dt * 9.80665 / heat_cap;                   // main.cpp:169
     d.dE[at] = dEl;
     if (l == NL - 1) d.Tsfc[c] = Tn * conv;                      // main.cpp:173
     if (l == 0) {
@@ -972,15 +994,15 @@ __device__ __forceinline__ void post_column(const Dev &d, int c, int l, const do
   if (on) {
     const double T = s_sorted[l] / conv;  // theta_to_t, main.cpp:131-139
     d.T[at] = T;
-    r = fabs(T - d.Tprev[at]);
+    r = fabs(T - in.Tprev);
     d.Tprev[at] = T;
     d.Ttau[at] = T;
-    const double vmr = d.rel_hum[at] * magnus_dev(T) / d.player[l];  // main.cpp:285-286
+    const double vmr = in.rel_hum * magnus_dev(T) / in.player;  // main.cpp:285-286
     double *gas = d.gas + (size_t)c * d.ngas * NL;
     if (d.mode == MODE_REPWVL)
       gas[0 * NL + l] = vmr;                    // H2O is read_tau's first species
     else
-      gas[1 * NL + l] = vmr / d.h2o_ref[l];     // lbl: tau_H2O is linear in the mixing ratio
+      gas[1 * NL + l] = vmr / in.h2o_ref;       // lbl: tau_H2O is linear in the mixing ratio
   }
 #pragma unroll
   for (int off = 16; off >= 1; off >>= 1) {  // lanes 0..31 cover the 20 layers; a NaN layer makes the residual NaN
@@ -1455,6 +1477,7 @@ __global__ __launch_bounds__(1024) void k_post(Dev d, int next_pre) {
   __shared__ double s_E[PSTRIDE];
   const int c = blockIdx.x;
   const int j = threadIdx.x & 63, q = threadIdx.x >> 6, P = blockDim.x >> 6;
+  const PostIn in = post_load(d, c, threadIdx.x, next_pre);  // (used by the first wave)
   if (j < PSTRIDE) {
     const double *p = d.partial + (size_t)c * d.nchunk * PSTRIDE + j;
     double acc = 0.0;
@@ -1480,7 +1503,34 @@ __global__ __launch_bounds__(1024) void k_post(Dev d, int next_pre) {
   __syncthreads();
   if (threadIdx.x >= 64) return;  // the rest is the first wave's: lane l = layer l (no block barrier below)
   __shared__ double s_scr[3 * NL];
-  post_column(d, c, threadIdx.x, s_E, s_scr, next_pre);
+  post_column(d, c, threadIdx.x, in, s_E, s_scr, next_pre);
+}
+
+// The same for few partial records per column (<= 16: the repwvl kernels, small lbl spectra): one WAVE per column,
+// four columns per block, no block barrier.
+__global__ __launch_bounds__(64 * WPB) void k_post_wave(Dev d, int next_pre) {
+  __shared__ double s_E[WPB][PSTRIDE];
+  __shared__ double s_scr[WPB][3 * NL];
+  const int lane = threadIdx.x & 63, wib = threadIdx.x >> 6;
+  const int c = blockIdx.x * WPB + wib;
+  if (c >= d.ncol) return;
+  const PostIn in = post_load(d, c, lane, next_pre);
+  if (lane < PSTRIDE) {
+    const double *p = d.partial + (size_t)c * d.nchunk * PSTRIDE + lane;
+    double v[16];
+#pragma unroll
+    for (int u = 0; u < 16; ++u) v[u] = (u < d.nchunk) ? p[(size_t)u * PSTRIDE] : 0.0;  // all loads in flight
+    double acc = 0.0;
+#pragma unroll
+    for (int u = 0; u < 16; ++u) acc += v[u];  // chunk order, as k_post
+    s_E[wib][lane] = acc;
+    if (lane < NLEV)
+      d.E_down[(size_t)c * NLEV + lane] = acc;
+    else
+      d.E_up[(size_t)c * NLEV + (lane - NLEV)] = acc;
+  }
+  __builtin_amdgcn_wave_barrier();
+  post_column(d, c, lane, in, s_E[wib], s_scr[wib], next_pre);
 }
 
 // output_conv view of one column (main.cpp:536-546) into scratch: adjusted T, sorted theta.
