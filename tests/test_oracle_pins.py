@@ -183,6 +183,56 @@ def test_product_ascii_loader_against_compiled_reference(rcm, tmp_path):
                                      C.byref(x), C.byref(y)) == -1
 
 
+def test_product_ascii_loader_random_files_against_compiled_reference(rcm, tmp_path):
+    """Seeded random files -- random shapes, separators (blanks, tabs, runs of both), comment lines in both styles,
+    trailing comments, blank lines, occasional ragged rows, words and stray signs among the numbers -- through the
+    product's loader and the reference's compiled ASCII_file2xy2D: same status, same matrices, bit for bit."""
+    ref = _ref_lib("libref_ascii.so")
+    dpp = C.POINTER(C.POINTER(C.c_double))
+    ref.ASCII_file2xy2D.argtypes = [C.c_char_p, C.POINTER(C.c_int), C.POINTER(C.c_int),
+                                    C.POINTER(C.POINTER(C.c_double)), C.POINTER(dpp)]
+    rng = np.random.default_rng(20260104)
+    seen = {0: 0, -5: 0}
+    for case in range(120):
+        nrow, ncol = int(rng.integers(1, 12)), int(rng.integers(1, 9))
+        lines = []
+        for r in range(nrow):
+            if rng.random() < 0.15:
+                lines.append(rng.choice(["% a comment 1 2 3", "# another 4 5", "", "   \t ", "%", "#x"]))
+            n = ncol + (int(rng.integers(-1, 2)) if rng.random() < 0.06 else 0)  # now and then a ragged row
+            toks = []
+            for _ in range(max(n, 1)):
+                u = rng.random()
+                if u < 0.04:
+                    toks.append(str(rng.choice(["abc", "nan", "inf", "-", "+", "1e", "0x10", "1.5.2", "--3", "7,5"])))
+                elif u < 0.5:
+                    toks.append(f"{rng.normal() * 10.0 ** int(rng.integers(-8, 8)):.{int(rng.integers(1, 17))}e}")
+                else:
+                    toks.append(repr(float(rng.integers(-1000, 1000)) / float(rng.integers(1, 50))))
+            sep = [" ", "\t", "  ", " \t ", "\t\t"]
+            line = str(rng.choice(["", " ", "\t"])) + "".join(t + str(rng.choice(sep)) for t in toks)
+            if rng.random() < 0.1:
+                line += str(rng.choice(["% tail 9 9", "# tail", "%"]))
+            lines.append(line)
+        text = "\n".join(lines) + ("\n" if rng.random() < 0.8 else "")
+        path = tmp_path / f"r{case}.asc"
+        path.write_text(text)
+        nx, ny = C.c_int(0), C.c_int(0)
+        x, y = C.POINTER(C.c_double)(), dpp()
+        st_ref = ref.ASCII_file2xy2D(str(path).encode(), C.byref(nx), C.byref(ny), C.byref(x), C.byref(y))
+        st, xs, ys = rcm.ascii_file2xy2D(str(path))
+        assert st == st_ref, (case, text)
+        seen[st] = seen.get(st, 0) + 1
+        if st == 0:
+            assert xs.shape == (nx.value,) and ys.shape == (nx.value, ny.value), (case, text)
+            xr = np.ctypeslib.as_array(x, (nx.value,)).copy() if nx.value else np.zeros(0)
+            yr = np.zeros((nx.value, 0)) if ny.value == 0 or nx.value == 0 else np.array(
+                [np.ctypeslib.as_array(y[i], (ny.value,)) for i in range(nx.value)]).reshape(nx.value, ny.value)
+            np.testing.assert_array_equal(xs, xr, err_msg=text)  # (NaN == NaN positionally)
+            np.testing.assert_array_equal(ys, yr, err_msg=text)
+    assert seen[0] >= 40 and seen[-5] >= 5, seen
+
+
 def test_host_abi_matches_oracle(rcm, olib, golden):
     """rcm_atm_load / rcm_column_init / rcm_solar_setup / rcm_rtab_load (host C++) == oracle (C)."""
     for atm_name in ("test.atm", "fpda.lbl.atm"):
