@@ -55,6 +55,8 @@ struct rcm_ensemble {
   std::vector<double> p_grid;
   std::vector<double> xsec_t;  // xsec re-laid out [t][s][p][w] (host copy: the per-layer table is re-derived with the grid)
   double *d_xp = nullptr;      // [layer][t][s][w]: xsec interpolated to the layer's mid pressure (derive_repwvl_layers)
+  double *d_tref_l = nullptr;  // [layer]: t_ref[ip[layer]]
+  std::vector<double> t_ref;   // host copy
   int *d_ip = nullptr;
   double *d_delP = nullptr, *d_numDens = nullptr;
   // timing
@@ -134,6 +136,9 @@ int derive_repwvl_layers(rcm_ensemble *h) {
     HIPCK(hipMemcpyAsync(h->d_xp, xp.data(), xp.size() * sizeof(double), hipMemcpyHostToDevice, h->stream));
     HIPCK(hipStreamSynchronize(h->stream));  // xp goes out of scope
   }
+  std::vector<double> tref_l(NL);
+  for (int l = 0; l < NL; ++l) tref_l[l] = h->t_ref[ip[l]];  // :229: the bracket's reference temperature per layer
+  HIPCK(hipMemcpyAsync(h->d_tref_l, tref_l.data(), NL * sizeof(double), hipMemcpyHostToDevice, h->stream));
   HIPCK(hipMemcpyAsync(h->d_ip, ip.data(), NL * sizeof(int), hipMemcpyHostToDevice, h->stream));
   HIPCK(hipMemcpyAsync(h->d_delP, delP.data(), NL * sizeof(double), hipMemcpyHostToDevice, h->stream));
   HIPCK(hipMemcpyAsync(h->d_numDens, numDens.data(), NL * sizeof(double), hipMemcpyHostToDevice, h->stream));
@@ -646,6 +651,7 @@ int rcm_set_repwvl_tables(rcm_ensemble *h, int n_tpert, int n_species, int n_wvl
     return fail(RCM_ERR_ARG, "rcm_set_repwvl_tables: NULL argument");
   if (n_species != RCM_NSPEC_REPWVL) return fail(RCM_ERR_ARG, "rcm_set_repwvl_tables: n_species must be 9");
   if (n_tpert < 2 || n_p < 2 || n_wvl < 1) return fail(RCM_ERR_ARG, "rcm_set_repwvl_tables: bad dimensions");
+  if (n_tpert > 16) return fail(RCM_ERR_ARG, "rcm_set_repwvl_tables: at most 16 temperature perturbations (the shipped tables have 9)");
   if (h->mode != rcm::MODE_NONE) return fail(RCM_ERR_STATE, "rcm_set_repwvl_tables: tables already set");
   if ((unsigned long long)n_tpert * n_species * n_p * n_wvl * sizeof(double) >= (1ull << 32))
     return fail(RCM_ERR_ARG, "rcm_set_repwvl_tables: the table must stay below 4 GiB (32-bit offsets in the kernel)");
@@ -674,7 +680,10 @@ int rcm_set_repwvl_tables(rcm_ensemble *h, int n_tpert, int n_species, int n_wvl
   int rc = 0;
   rc = rc ? rc : dev_upload(h, (double **)&d.xsec, xt.data(), xt.size());
   rc = rc ? rc : dev_alloc(h, &h->d_xp, (size_t)NL * n_tpert * n_species * n_wvl);
+  rc = rc ? rc : dev_alloc(h, &h->d_tref_l, (size_t)NL);
   d.xp = h->d_xp;
+  d.tref_l = h->d_tref_l;
+  h->t_ref.assign(t_ref, t_ref + n_p);
   rc = rc ? rc : dev_upload(h, (double **)&d.t_ref, t_ref, (size_t)n_p);
   rc = rc ? rc : dev_upload(h, (double **)&d.t_pert, t_pert, (size_t)n_tpert);
   rc = rc ? rc : dev_upload(h, (double **)&d.pnum, pnum.data(), (size_t)n_wvl);

@@ -98,6 +98,7 @@ struct Dev {
   // repwvl: xsec[t][s][p][w] (wavelength fastest)
   const double *xsec, *t_ref, *t_pert, *delP, *numDens, *pnum, *lam5, *lkb;
   const double *xp;  // [layer][t][s][w]: xsec interpolated to the layer's mid pressure (host, with the grid)
+  const double *tref_l;  // [layer]: t_ref[ip[layer]], the reference temperature of the layer's pressure bracket (host)
   const double *rw_xc, *rw_sc;  // per wavelength: h*c/(lambda*kB) and pnum/lam5/1e9 (planck_mono_fast), host-formed
   const int *ip;
   int n_tpert, n_species, n_p, n_wvl;
@@ -784,6 +785,26 @@ struct RepwvlPairLds {
 __device__ __forceinline__ void repwvl_pair_image_from(const Dev &d, int col, int lane, RepwvlPairLds &s,
                                                        const double *Tl, const double *Ttau, double Tsfc,
                                                        const double *h2o) {
+  // Everything the image needs from HBM is requested FIRST and together -- the mixing ratios (six per lane), the
+  // temperature perturbations of the table (<= 16, wave-uniform), the layer's temperatures and constants -- so that
+  // the build waits for memory once (it was a chain of five dependent round trips and cost the flattened kernel a
+  // fifth of its time: ablation builds, profiles/README.md).
+  constexpr int kPerLane = (2 * RCM_NSPEC_REPWVL * NH + 63) / 64;
+  double vmr[kPerLane];
+#pragma unroll
+  for (int m = 0; m < kPerLane; ++m) {
+    const int i = lane + 64 * m;
+    const int q = i / (RCM_NSPEC_REPWVL * NH), r = i - q * (RCM_NSPEC_REPWVL * NH);
+    const int sp = r / NH, k = r - sp * NH;
+    const int layer = q ? NL - 1 - k : k;
+    vmr[m] = (i < 2 * RCM_NSPEC_REPWVL * NH)
+                 ? (sp == 0 ? h2o[layer] : d.gas[((size_t)col * RCM_NSPEC_REPWVL + sp) * NL + layer])
+                 : 0.0;
+  }
+  constexpr int kMaxTpert = 16;  // rcm_set_repwvl_tables checks n_tpert <= 16 (the shipped tables: 9)
+  double tp[kMaxTpert];
+#pragma unroll
+  for (int j = 0; j < kMaxTpert; ++j) tp[j] = j < d.n_tpert ? d.t_pert[j] : 0.0;
   if (lane < 2 * (NH + 1)) {
     const int q = lane / (NH + 1), k = lane - q * (NH + 1);
     if (k == NH) {
@@ -791,29 +812,50 @@ __device__ __forceinline__ void repwvl_pair_image_from(const Dev &d, int col, in
       s.rT[q][k] = 1.0 / Tsfc;
     } else {
       const int layer = q ? NL - 1 - k : k;
-      s.T[q][k] = Tl[layer];
-      s.rT[q][k] = 1.0 / s.T[q][k];
-      const double midT = Ttau[layer];  // :217 (prop_at_Lev == 0)
-      const int ip = d.ip[layer];
-      const double tr = d.t_ref[ip];
-      const double *tp = d.t_pert;
-      const int it = lower_pos_dev([&](int j) { return tr + tp[j]; }, d.n_tpert, midT);  // :229-232
-      const double t0 = tr + tp[it], t1 = tr + tp[it + 1];
+      const double Tlay = Tl[layer], midT = Ttau[layer];  // :217 (prop_at_Lev == 0)
+      const double tr = d.tref_l[layer], nd = d.numDens[layer];
+      const double cloud = (layer == d.cloud_layer[col]) ? d.cloud_tau[col] : 0.0;
+      s.T[q][k] = Tlay;
+      s.rT[q][k] = 1.0 / Tlay;
+      // LowerPos(t_ref[ip] + t_pert, midT), repwvl_thermal.cpp:19-45 / :229-232, on the register copy: first change of
+      // sign between neighbours, else the last bracket; t0, t1 = the bracket's temperatures
+      int it = 0;
+      double t0 = tr + tp[0], t1 = tr + tp[1];
+      {
+        bool found = false;
+        double gprev = tr + tp[0];
+        int sign = sgn_dev(gprev - midT);
+#pragma unroll
+        for (int pidx = 1; pidx < kMaxTpert; ++pidx) {
+          if (pidx < d.n_tpert && !found) {
+            const double g = tr + tp[pidx];
+            const int sg = sgn_dev(g - midT);
+            if (sign != sg || pidx == d.n_tpert - 1) {
+              found = true;
+              it = pidx - 1;
+              t0 = gprev, t1 = g;
+            }
+            sign = sg;
+            gprev = g;
+          }
+        }
+      }
       s.xoff[q][k] = (unsigned)((((size_t)layer * d.n_tpert + it) * d.n_species) * d.n_wvl * sizeof(double));
       const double dT = (midT - t0) / (t1 - t0);  // :239
-      const double nd = d.numDens[layer];
       s.wA[q][k] = nd * (1.0 - dT), s.wB[q][k] = nd * dT;
-      s.cloud[q][k] = (layer == d.cloud_layer[col]) ? d.cloud_tau[col] : 0.0;
+      s.cloud[q][k] = cloud;
     }
   }
   __builtin_amdgcn_wave_barrier();  // one wave builds an image: its LDS operations execute in program order
-  for (int i = lane; i < 2 * RCM_NSPEC_REPWVL * NH; i += 64) {
-    const int q = i / (RCM_NSPEC_REPWVL * NH), r = i - q * (RCM_NSPEC_REPWVL * NH);
-    const int sp = r / NH, k = r - sp * NH;
-    const int layer = q ? NL - 1 - k : k;
-    const double vmr = sp == 0 ? h2o[layer] : d.gas[((size_t)col * RCM_NSPEC_REPWVL + sp) * NL + layer];
-    s.cA[q][sp][k] = s.wA[q][k] * vmr;  // :244 and :246 folded into the interpolation weights
-    s.cB[q][sp][k] = s.wB[q][k] * vmr;
+#pragma unroll
+  for (int m = 0; m < kPerLane; ++m) {
+    const int i = lane + 64 * m;
+    if (i < 2 * RCM_NSPEC_REPWVL * NH) {
+      const int q = i / (RCM_NSPEC_REPWVL * NH), r = i - q * (RCM_NSPEC_REPWVL * NH);
+      const int sp = r / NH, k = r - sp * NH;
+      s.cA[q][sp][k] = s.wA[q][k] * vmr[m];  // :244 and :246 folded into the interpolation weights
+      s.cB[q][sp][k] = s.wB[q][k] * vmr[m];
+    }
   }
 }
 
@@ -1053,7 +1095,12 @@ __global__ __launch_bounds__(64 * FWPB, RCM_FLAT_LB) void k_rt_repwvl_flat(Dev d
     ncb = (int)(min(blk0 + FWPB * 32 - 1, nflat - 1) / nw) - cb_first + 1;
   }
   RCM_PT_STAMP(16);
+#ifdef RCM_DBG_NOIMAGE  // ablation builds only: all-zero images (valid offsets, no work)
+  for (int i = threadIdx.x; i < (int)((size_t)ncb * sizeof(RepwvlPairLds) / 8); i += blockDim.x)
+    reinterpret_cast<double *>(imgs)[i] = 0.0;
+#else
   for (int sl = wib; sl < ncb; sl += FWPB) repwvl_pair_image(d, cb_first + sl, lane, imgs[sl]);
+#endif
   __syncthreads();
   RCM_PT_STAMP(17);
 
@@ -1073,25 +1120,35 @@ __global__ __launch_bounds__(64 * FWPB, RCM_FLAT_LB) void k_rt_repwvl_flat(Dev d
   // ---- segmented reduction: one masked butterfly per column of the wave's 32 items (fixed order)
   // even lane: acc1[j] = E_down[j] (j = 0..10), acc2[k] = E_up[k] (k = 0..9)
   // odd lane:  acc1[j] = E_up[20-j],           acc2[k] = E_down[20-k]
+#ifdef RCM_DBG_NOREDUCE  // ablation builds only
+  if (acc1[3] == 1.2345) d.partial[0] = acc2[1];
+  return;
+#endif
   const int c_first = (int)(flat0 / nw), c_last = (int)(min(flat0 + 31, nflat - 1) / nw);
-  const bool w0 = lane == PairRw::lane_of(0, 0), w1 = lane == PairRw::lane_of(0, 1);
+  // The 42 sums of a record leave the wave in ONE store instruction (336 contiguous bytes from lanes 0..41), not in
+  // 21 instructions of two lanes each: a store instruction costs the texture path the same whatever its lane count,
+  // and 1.3 million of them per step were 45 us of the kernel (ablation builds).  The two lanes that hold the
+  // sums in the fixed order (pair 0 of either parity) put them in record order into the wave's staging row first.
+  const bool writer = lane == PairRw::lane_of(0, 0) || lane == PairRw::lane_of(0, 1);
+  double *E = &st[0][0];  // the staging columns are free after the angle loop
   for (int c = c_first; c <= c_last; ++c) {
     const bool mine = col == c;
     const long seg0 = max((long)c * nw, flat0);
     const long slot = (seg0 - (long)c * nw + 31) / 32;
-    double *oEd = d.partial + ((size_t)c * d.nchunk + slot) * PSTRIDE, *oEu = oEd + NLEV;
+    double *out = d.partial + ((size_t)c * d.nchunk + slot) * PSTRIDE;  // E_down[21], E_up[21]
 #pragma unroll
-    for (int j = 0; j <= NH; ++j) {
+    for (int j = 0; j <= NH; ++j) {  // even lane: E_down[j]; odd lane: E_up[20-j]
       const double v = PairRw::sum<5>(mine ? acc1[j] : 0.0);
-      if (w0) oEd[j] = v;
-      if (w1) oEu[NL - j] = v;
+      if (writer) E[p ? NLEV + NL - j : j] = v;
     }
 #pragma unroll
-    for (int k = 0; k < NH; ++k) {
+    for (int k = 0; k < NH; ++k) {   // even lane: E_up[k]; odd lane: E_down[20-k]
       const double v = PairRw::sum<5>(mine ? acc2[k] : 0.0);
-      if (w0) oEu[k] = v;
-      if (w1) oEd[NL - k] = v;
+      if (writer) E[p ? NL - k : NLEV + k] = v;
     }
+    __builtin_amdgcn_wave_barrier();  // one wave: its LDS operations execute in program order
+    if (lane < PSTRIDE) out[lane] = E[lane];
+    __builtin_amdgcn_wave_barrier();
   }
   RCM_PT_STAMP(18);
 }
