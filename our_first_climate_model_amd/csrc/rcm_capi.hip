@@ -467,6 +467,9 @@ int rcm_create(int ncol, int nlayer, int nangle, int device, void *stream, rcm_e
   rc = rc ? rc : dev_alloc(h, (double **)&d.cloud_tau, (size_t)ncol);
   rc = rc ? rc : dev_alloc(h, (int **)&d.cloud_layer, (size_t)ncol);
   rc = rc ? rc : dev_alloc(h, &d.resid, (size_t)ncol);
+  rc = rc ? rc : dev_alloc(h, &d.brk_w, 2 * nT);
+  rc = rc ? rc : dev_alloc(h, &d.brk_off, nT);
+  rc = rc ? rc : dev_alloc(h, &d.rT, nE);
   rc = rc ? rc : dev_alloc(h, &d.Tprev, nT);
   rc = rc ? rc : dev_alloc(h, (double **)&d.player, (size_t)NL);
   rc = rc ? rc : dev_alloc(h, (double **)&d.conv, (size_t)NL);

@@ -99,6 +99,11 @@ struct Dev {
   const double *xsec, *t_ref, *t_pert, *delP, *numDens, *pnum, *lam5, *lkb;
   const double *xp;  // [layer][t][s][w]: xsec interpolated to the layer's mid pressure (host, with the grid)
   const double *tref_l;  // [layer]: t_ref[ip[layer]], the reference temperature of the layer's pressure bracket (host)
+  // repwvl, per column and layer, written at the start of every iteration (k_pre / post_column) for the flattened
+  // kernel's image build: the temperature bracket of read_tau as two weights and a table offset, and 1/T
+  double *brk_w;      // [ncol][2][NL]: numDens*(1-delT), numDens*delT
+  unsigned *brk_off;  // [ncol][NL]: byte offset of xp[l][it][0][0]
+  double *rT;         // [ncol][NL+1]: 1/Tlayer (adjusted), 1/T_surface
   const double *rw_xc, *rw_sc;  // per wavelength: h*c/(lambda*kB) and pnum/lam5/1e9 (planck_mono_fast), host-formed
   const int *ip;
   int n_tpert, n_species, n_p, n_wvl;
@@ -778,6 +783,62 @@ struct RepwvlPairLds {
   unsigned xoff[2][NH];  // byte offset of xp[l][it][0][0]: the layer's temperature bracket (:229-232)
 };
 
+// The temperature bracket of read_tau for one layer (repwvl_thermal.cpp:229-239): it = LowerPos(t_ref[ip] +
+// t_pert, midT) (:19-45: first change of sign between neighbours, else the last bracket) and delT; as the
+// weights numDens*(1-delT), numDens*delT (numDens: :202, :246) and the byte offset of xp[layer][it][0][0].
+// tp = the table's temperature perturbations in registers (<= 16; rcm_set_repwvl_tables checks).
+constexpr int kMaxTpert = 16;
+
+__device__ __forceinline__ void load_tpert(const Dev &d, double (&tp)[kMaxTpert]) {
+#pragma unroll
+  for (int j = 0; j < kMaxTpert; ++j) tp[j] = j < d.n_tpert ? d.t_pert[j] : 0.0;
+}
+
+__device__ __forceinline__ void repwvl_bracket(const Dev &d, const double (&tp)[kMaxTpert], int layer, double tr, double nd,
+                                               double midT, double *wA, double *wB, unsigned *xoff) {
+  int it = 0;
+  double t0 = tr + tp[0], t1 = tr + tp[1];
+  bool found = false;
+  double gprev = tr + tp[0];
+  int sign = sgn_dev(gprev - midT);
+#pragma unroll
+  for (int pidx = 1; pidx < kMaxTpert; ++pidx) {
+    if (pidx < d.n_tpert && !found) {
+      const double g = tr + tp[pidx];
+      const int sg = sgn_dev(g - midT);
+      if (sign != sg || pidx == d.n_tpert - 1) {
+        found = true;
+        it = pidx - 1;
+        t0 = gprev, t1 = g;
+      }
+      sign = sg;
+      gprev = g;
+    }
+  }
+  const double dT = (midT - t0) / (t1 - t0);  // :239
+  *wA = nd * (1.0 - dT), *wB = nd * dT;
+  *xoff = (unsigned)((((size_t)layer * d.n_tpert + it) * d.n_species) * d.n_wvl * sizeof(double));
+}
+
+// Start of an iteration, repwvl: lane l = layer l of column c stores the layer's bracket for the optical depths of
+// this iteration (temperature midT) and 1/T of the adjusted profile; lane NL stores 1/T_surface.
+__device__ __forceinline__ void repwvl_bracket_store(const Dev &d, int c, int l, double Tadj, double midT, double Tsfc) {
+  if (d.mode != MODE_REPWVL) return;
+  double tp[kMaxTpert];
+  load_tpert(d, tp);
+  if (l < NL) {
+    double wA, wB;
+    unsigned xoff;
+    repwvl_bracket(d, tp, l, d.tref_l[l], d.numDens[l], midT, &wA, &wB, &xoff);
+    d.brk_w[((size_t)c * 2 + 0) * NL + l] = wA;
+    d.brk_w[((size_t)c * 2 + 1) * NL + l] = wB;
+    d.brk_off[(size_t)c * NL + l] = xoff;
+    d.rT[(size_t)c * NLEV + l] = 1.0 / Tadj;
+  } else if (l == NL) {
+    d.rT[(size_t)c * NLEV + NL] = 1.0 / Tsfc;
+  }
+}
+
 // Fills the LDS image of column `col`: per (parity, position) the temperature bracket of read_tau
 // (repwvl_thermal.cpp:229-239), the layer constants, the mixing ratios.  Called by a whole wave.
 // Tl / Ttau [NL], Tsfc and h2o [NL] (species 0, the row the feedback rewrites) come from the caller: the
@@ -801,10 +862,8 @@ __device__ __forceinline__ void repwvl_pair_image_from(const Dev &d, int col, in
                  ? (sp == 0 ? h2o[layer] : d.gas[((size_t)col * RCM_NSPEC_REPWVL + sp) * NL + layer])
                  : 0.0;
   }
-  constexpr int kMaxTpert = 16;  // rcm_set_repwvl_tables checks n_tpert <= 16 (the shipped tables: 9)
   double tp[kMaxTpert];
-#pragma unroll
-  for (int j = 0; j < kMaxTpert; ++j) tp[j] = j < d.n_tpert ? d.t_pert[j] : 0.0;
+  load_tpert(d, tp);
   if (lane < 2 * (NH + 1)) {
     const int q = lane / (NH + 1), k = lane - q * (NH + 1);
     if (k == NH) {
@@ -817,32 +876,7 @@ __device__ __forceinline__ void repwvl_pair_image_from(const Dev &d, int col, in
       const double cloud = (layer == d.cloud_layer[col]) ? d.cloud_tau[col] : 0.0;
       s.T[q][k] = Tlay;
       s.rT[q][k] = 1.0 / Tlay;
-      // LowerPos(t_ref[ip] + t_pert, midT), repwvl_thermal.cpp:19-45 / :229-232, on the register copy: first change of
-      // sign between neighbours, else the last bracket; t0, t1 = the bracket's temperatures
-      int it = 0;
-      double t0 = tr + tp[0], t1 = tr + tp[1];
-      {
-        bool found = false;
-        double gprev = tr + tp[0];
-        int sign = sgn_dev(gprev - midT);
-#pragma unroll
-        for (int pidx = 1; pidx < kMaxTpert; ++pidx) {
-          if (pidx < d.n_tpert && !found) {
-            const double g = tr + tp[pidx];
-            const int sg = sgn_dev(g - midT);
-            if (sign != sg || pidx == d.n_tpert - 1) {
-              found = true;
-              it = pidx - 1;
-              t0 = gprev, t1 = g;
-            }
-            sign = sg;
-            gprev = g;
-          }
-        }
-      }
-      s.xoff[q][k] = (unsigned)((((size_t)layer * d.n_tpert + it) * d.n_species) * d.n_wvl * sizeof(double));
-      const double dT = (midT - t0) / (t1 - t0);  // :239
-      s.wA[q][k] = nd * (1.0 - dT), s.wB[q][k] = nd * dT;
+      repwvl_bracket(d, tp, layer, tr, nd, midT, &s.wA[q][k], &s.wB[q][k], &s.xoff[q][k]);
       s.cloud[q][k] = cloud;
     }
   }
@@ -855,6 +889,47 @@ __device__ __forceinline__ void repwvl_pair_image_from(const Dev &d, int col, in
       const int sp = r / NH, k = r - sp * NH;
       s.cA[q][sp][k] = s.wA[q][k] * vmr[m];  // :244 and :246 folded into the interpolation weights
       s.cB[q][sp][k] = s.wB[q][k] * vmr[m];
+    }
+  }
+}
+
+// The same image from the brackets k_pre / post_column stored for this iteration (repwvl_bracket_store): loads and
+// products only.  The flattened kernel builds every column's image 2.3 times per iteration (once per block that
+// touches it); the search and the divisions are done once per column.
+__device__ __forceinline__ void repwvl_pair_image_stored(const Dev &d, int col, int lane, RepwvlPairLds &s) {
+  constexpr int kPerLane = (2 * RCM_NSPEC_REPWVL * NH + 63) / 64;
+  double vmr[kPerLane], wa[kPerLane], wb[kPerLane];
+#pragma unroll
+  for (int m = 0; m < kPerLane; ++m) {
+    const int i = min(lane + 64 * m, 2 * RCM_NSPEC_REPWVL * NH - 1);
+    const int q = i / (RCM_NSPEC_REPWVL * NH), r = i - q * (RCM_NSPEC_REPWVL * NH);
+    const int sp = r / NH, k = r - sp * NH;
+    const int layer = q ? NL - 1 - k : k;
+    vmr[m] = d.gas[((size_t)col * RCM_NSPEC_REPWVL + sp) * NL + layer];
+    wa[m] = d.brk_w[((size_t)col * 2 + 0) * NL + layer];
+    wb[m] = d.brk_w[((size_t)col * 2 + 1) * NL + layer];
+  }
+  if (lane < 2 * (NH + 1)) {
+    const int q = lane / (NH + 1), k = lane - q * (NH + 1);
+    const int layer = q ? NL - 1 - k : k;
+    if (k == NH) {
+      s.T[q][k] = d.Tsfc[col];
+      s.rT[q][k] = d.rT[(size_t)col * NLEV + NL];
+    } else {
+      s.T[q][k] = d.T[(size_t)col * NL + layer];
+      s.rT[q][k] = d.rT[(size_t)col * NLEV + layer];
+      s.xoff[q][k] = d.brk_off[(size_t)col * NL + layer];
+      s.cloud[q][k] = (layer == d.cloud_layer[col]) ? d.cloud_tau[col] : 0.0;
+    }
+  }
+#pragma unroll
+  for (int m = 0; m < kPerLane; ++m) {
+    const int i = lane + 64 * m;
+    if (i < 2 * RCM_NSPEC_REPWVL * NH) {
+      const int q = i / (RCM_NSPEC_REPWVL * NH), r = i - q * (RCM_NSPEC_REPWVL * NH);
+      const int sp = r / NH, k = r - sp * NH;
+      s.cA[q][sp][k] = wa[m] * vmr[m];  // :244 and :246 folded into the interpolation weights
+      s.cB[q][sp][k] = wb[m] * vmr[m];
     }
   }
 }
@@ -1032,13 +1107,14 @@ __device__ __forceinline__ void post_column(const Dev &d, int c, int l, const Po
     s_sorted[rank] = th;                 // sort(theta, greater), main.cpp:538
   }
   __builtin_amdgcn_wave_barrier();
-  double r = 0.0;
+  double r = 0.0, Tadj = 0.0;
   if (on) {
     const double T = s_sorted[l] / conv;  // theta_to_t, main.cpp:131-139
     d.T[at] = T;
     r = fabs(T - in.Tprev);
     d.Tprev[at] = T;
     d.Ttau[at] = T;
+    Tadj = T;
     const double vmr = in.rel_hum * magnus_dev(T) / in.player;  // main.cpp:285-286
     double *gas = d.gas + (size_t)c * d.ngas * NL;
     if (d.mode == MODE_REPWVL)
@@ -1052,6 +1128,10 @@ __device__ __forceinline__ void post_column(const Dev &d, int c, int l, const Po
     r = (o > r || o != o) ? o : r;
   }
   if (l == 0) d.resid[c] = r;
+  if (l <= NL) {  // the next iteration's brackets; T_surface was formed by lane NL-1 above
+    const double Tsfc = __shfl(Tn * conv, NL - 1, 64);
+    repwvl_bracket_store(d, c, l, Tadj, Tadj, Tsfc);
+  }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1099,7 +1179,7 @@ __global__ __launch_bounds__(64 * FWPB, RCM_FLAT_LB) void k_rt_repwvl_flat(Dev d
   for (int i = threadIdx.x; i < (int)((size_t)ncb * sizeof(RepwvlPairLds) / 8); i += blockDim.x)
     reinterpret_cast<double *>(imgs)[i] = 0.0;
 #else
-  for (int sl = wib; sl < ncb; sl += FWPB) repwvl_pair_image(d, cb_first + sl, lane, imgs[sl]);
+  for (int sl = wib; sl < ncb; sl += FWPB) repwvl_pair_image_stored(d, cb_first + sl, lane, imgs[sl]);
 #endif
   __syncthreads();
   RCM_PT_STAMP(17);
@@ -1448,9 +1528,10 @@ __global__ __launch_bounds__(64 * WPB) void k_pre(Dev d, int first) {
   const int c = blockIdx.x * WPB + wib;
   const bool on = c < d.ncol && lane < NL;
   const size_t at = (size_t)(on ? c : 0) * NL + (on ? lane : 0);
-  double T = 0.0, th = 0.0, conv = 1.0;
+  double T = 0.0, Tpre = 0.0, th = 0.0, conv = 1.0;
   if (on) {
     T = d.T[at];
+    Tpre = T;
     conv = d.conv[lane];
     if (first) d.Ttau[at] = T;  // main.cpp:500: the first optical depths come from the pre-adjustment profile
     th = T * conv;              // t_to_theta, main.cpp:123-129
@@ -1480,6 +1561,8 @@ __global__ __launch_bounds__(64 * WPB) void k_pre(Dev d, int first) {
     r = (o > r || o != o) ? o : r;
   }
   if (on && lane == 0) d.resid[c] = first ? 1e300 : r;
+  if (c < d.ncol && lane <= NL)  // this iteration's optical depths are interpolated at Ttau: T before (first) / after the adjustment
+    repwvl_bracket_store(d, c, lane, T, first ? Tpre : T, lane == NL ? d.Tsfc[c] : 0.0);
   if (on && !first) {
     d.Ttau[at] = T;
     const double vmr = d.rel_hum[at] * magnus_dev(T) / d.player[lane];  // main.cpp:285-286
