@@ -47,9 +47,6 @@ constexpr int WPB = 4;       // waves per block = columns per block (one per SIM
 #ifndef RCM_PLK_UNROLL
 #define RCM_PLK_UNROLL 1  // independent band-Planck evaluations in flight
 #endif
-#ifndef RCM_LBL_TAU_UNROLL
-#define RCM_LBL_TAU_UNROLL 2  // layers of the lbl optical-depth stage in flight (5 table loads each)
-#endif
 #ifndef RCM_RW_TAU_UNROLL
 #define RCM_RW_TAU_UNROLL 1  // layers of the repwvl optical-depth stage in flight (20 table loads each)
 #endif
@@ -547,18 +544,10 @@ __device__ __forceinline__ void pair_chain(const Dev &d, const double (&t)[NH], 
 // a1 = -log2(e)/mu of the exponential to evaluate and code = 4*n + mode, mode 0: plain root n, 1: a1 is the
 // generator of (n = 3m, 5m), u^3 is parked in the lane's LDS column st (free during the angle loop),
 // 2: n = 5m, transmissions come back from st.
-// A job that rides along with the angle loop: begin(s) at the start of schedule step s, end(s) after its chain (a few
-// hundred VALU instructions later).  The lbl kernel uses it to fetch the NEXT pass's table values under the angle
-// loop of the current one (LblPrefetch); NoSide does nothing.
-struct NoSide {
-  __device__ __forceinline__ void begin(int) {}
-  __device__ __forceinline__ void end(int) {}
-};
-
-template <class P, int CUBE, class Side = NoSide>
+template <class P, int CUBE>
 __device__ __forceinline__ void pair_all_angles(const Dev &d, const double (&tau)[NH], const double (&B)[NH],
                                                 double Linit, double (*st)[64], int lane, double (&acc1)[NH + 1],
-                                                double (&acc2)[NH], Side side = Side()) {
+                                                double (&acc2)[NH]) {
   const int na = d.nangle;
   PairSrc src;
   pair_source<P>(B, Linit, d.ang[2 * na], src, st, lane, acc1, acc2);
@@ -573,7 +562,6 @@ __device__ __forceinline__ void pair_all_angles(const Dev &d, const double (&tau
   } else {
     const double *sched = d.ang + 2 * na + 1;
     for (int s = 0; s < d.nsched; ++s) {
-      side.begin(s);
       const double a1 = sched[2 * s];
       const int code = (int)__double_as_longlong(sched[2 * s + 1]);
       double t[NH];
@@ -593,7 +581,6 @@ __device__ __forceinline__ void pair_all_angles(const Dev &d, const double (&tau
         }
       }
       pair_chain<P, 4>(d, t, src, &st[NH][lane], code >> 2, acc1, acc2);
-      side.end(s);
     }
   }
 }
@@ -677,57 +664,19 @@ __device__ __forceinline__ LblAddr lbl_pair_addr(const Dev &d, int p) {
 // staging column st[0..9][lane].  THE optical-depth arithmetic of the production kernel; k_tau_pair dumps it.
 __device__ __forceinline__ void lbl_pair_tau(const PairLds &s, int p, const char *const (&sbase)[RCM_NSPEC_LBL],
                                              unsigned off, unsigned rstep, double (*st)[64], int lane) {
-#pragma unroll RCM_LBL_TAU_UNROLL
+#pragma unroll 2
   for (int k = 0; k < NH; ++k, off += rstep) {  // rolled: bounds the loads (and VGPRs) in flight
     double a = 0.0;
 #pragma unroll
-#ifdef RCM_DBG_NOLOAD  // ablation builds only: every lane reads one address
-    for (int sp = 0; sp < RCM_NSPEC_LBL; ++sp) a = fma(s.gas[p][sp][k], *(const double *)(sbase[sp] + (off & 0u)), a);
-#else
     for (int sp = 0; sp < RCM_NSPEC_LBL; ++sp) a = fma(s.gas[p][sp][k], *(const double *)(sbase[sp] + off), a);
-#endif
     st[k][lane] = clamp_tau(a + s.cloud[p][k]);  // + 0.0 leaves the other layers as they are
   }
 }
-
-// The optical depths of the NEXT pass, one layer per schedule step of the current pass's angle loop: the five table
-// loads of layer s are issued at the start of step s and used after its chain, so their latency (an L2 or HBM round
-// trip per two layers before: -13 % kernel time with the loads taken out, ablation build) hides under ~300 VALU
-// instructions.  The result waits in the wave's second staging column.  Ten more VGPRs for the duration of a step.
-#ifndef RCM_LBL_PREFETCH
-#define RCM_LBL_PREFETCH 1
-#endif
-struct LblPrefetch {
-  const PairLds *s;
-  const char *sbase[RCM_NSPEC_LBL];
-  int p, lane;
-  unsigned off0, rstep;  // byte offset of the lane's first row at the next pass's band, row step
-  double (*st2)[64];
-  double x[RCM_NSPEC_LBL];
-  __device__ __forceinline__ void begin(int k) {
-    if (k < NH) {
-      const unsigned off = off0 + (unsigned)k * rstep;
-#pragma unroll
-      for (int sp = 0; sp < RCM_NSPEC_LBL; ++sp) x[sp] = *(const double *)(sbase[sp] + off);
-    }
-  }
-  __device__ __forceinline__ void end(int k) {
-    if (k < NH) {
-      double a = 0.0;
-#pragma unroll
-      for (int sp = 0; sp < RCM_NSPEC_LBL; ++sp) a = fma(s->gas[p][sp][k], x[sp], a);
-      st2[k][lane] = clamp_tau(a + s->cloud[p][k]);
-    }
-  }
-};
 
 template <int CUBE>
 __global__ __launch_bounds__(64 * WPB, RCM_PAIR_LB) void k_rt_lbl_pair(Dev d) {
   __shared__ PairLds s_col[WPB];
   __shared__ double s_stage[WPB][NH + 1][64];
-#if RCM_LBL_PREFETCH
-  __shared__ double s_stage2[WPB][NH][64];  // the next pass's optical depths
-#endif
   const int lane = threadIdx.x & 63;
   const int wib = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   // work item = (chunk, column), column fastest: the waves of a block and neighbouring blocks share
@@ -765,30 +714,12 @@ __global__ __launch_bounds__(64 * WPB, RCM_PAIR_LB) void k_rt_lbl_pair(Dev d) {
   const long b1 = min(b0 + (long)d.chunk_len, (long)d.nspec);
   const LblAddr ad = lbl_pair_addr(d, p);
 
-#if RCM_LBL_PREFETCH
-  constexpr bool kPrefetch = CUBE != 0;  // (the schedule loop carries it)
-#else
-  constexpr bool kPrefetch = false;
-#endif
-#if RCM_LBL_PREFETCH
-  double(*st2)[64] = s_stage2[wib];
-  if (kPrefetch && b0 + PairLbl::index(lane) < b1)  // the first pass's optical depths
-    lbl_pair_tau(s, p, ad.sbase, ad.row0 + (unsigned)(b0 + PairLbl::index(lane)) * 8u, ad.rstep, st2, lane);
-#endif
   for (long b = b0 + PairLbl::index(lane); b < b1; b += 32) {  // main.cpp:329: 32 bands per wave pass
     // ---- optical depths of the lane's ten layers (lbl composition + cloud, main.cpp:266-274)
     double tau[NH];
-#if RCM_LBL_PREFETCH
-    if constexpr (kPrefetch) {
+    lbl_pair_tau(s, p, ad.sbase, ad.row0 + (unsigned)b * 8u, ad.rstep, st, lane);
 #pragma unroll
-      for (int k = 0; k < NH; ++k) tau[k] = st2[k][lane];
-    } else
-#endif
-    {
-      lbl_pair_tau(s, p, ad.sbase, ad.row0 + (unsigned)b * 8u, ad.rstep, st, lane);
-#pragma unroll
-      for (int k = 0; k < NH; ++k) tau[k] = st[k][lane];
-    }
+    for (int k = 0; k < NH; ++k) tau[k] = st[k][lane];
     // ---- band Planck source of the lane's ten layers and of the surface (cplkavg.cpp:124-243)
     const double wnumhi = d.lbl_wnum[b];      // cplkavg.cpp:141
     const double wnumlo = d.lbl_wnum[b + 1];  // cplkavg.cpp:142
@@ -826,22 +757,7 @@ __global__ __launch_bounds__(64 * WPB, RCM_PAIR_LB) void k_rt_lbl_pair(Dev d) {
 #pragma unroll
     for (int k = 0; k < NH; ++k) B[k] = st[k][lane];
     const double Linit = p ? st[NH][lane] : 0.0;  // main.cpp:300-301
-#if RCM_LBL_PREFETCH
-    if constexpr (kPrefetch) {
-      const long bn = b + 32 < b1 ? b + 32 : b;  // the last pass fetches its own band again (valid address, unused)
-      LblPrefetch side;
-      side.s = &s, side.p = p, side.lane = lane, side.st2 = st2;
-#pragma unroll
-      for (int sp = 0; sp < RCM_NSPEC_LBL; ++sp) side.sbase[sp] = ad.sbase[sp];
-      side.off0 = ad.row0 + (unsigned)bn * 8u, side.rstep = ad.rstep;
-      pair_all_angles<PairLbl, CUBE>(d, tau, B, Linit, st, lane, acc1, acc2, side);
-      for (int k = d.nsched; k < NH; ++k) {  // fewer schedule steps than layers (few angles): the rest here
-        side.begin(k);
-        side.end(k);
-      }
-    } else
-#endif
-      pair_all_angles<PairLbl, CUBE>(d, tau, B, Linit, st, lane, acc1, acc2);
+    pair_all_angles<PairLbl, CUBE>(d, tau, B, Linit, st, lane, acc1, acc2);
   }
 
   store_pair_partial<PairLbl>(d, col, chunk, lane, valid, acc1, acc2);
