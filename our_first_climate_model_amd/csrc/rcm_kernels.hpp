@@ -363,14 +363,17 @@ __global__ __launch_bounds__(64 * WPB, RCM_LB) void k_rt_lbl(Dev d) {
 //   points 0..15 and 16..31 of a pass, lanes 16..31 and 48..63 the "odd" halves (layers 19..10) of the same points;
 //   partners are 16 lanes apart and the hand-over is a ds_swizzle (LDS crossbar, no LDS memory, no VALU
 //   instruction, but ~100 cycles of latency inside the dependent chain of an angle).
-// Measured on one box (tools/ab_libs.py): lbl kernel, 50 loads per pass: Pair<0> 71.1 ms, Pair<1> 72.4 ms per
-// 2048-column launch; flattened repwvl kernel, 100 loads per pass: Pair<0> 407 us, Pair<1> 380 us per step.  So
-// the lbl kernel pairs adjacent lanes and the repwvl kernels rows of 16 (RCM_LBL_LAYOUT / RCM_RW_LAYOUT).
+// Pair<2> alternates HALF-ROWS OF 8 LANES (lanes 0..7 "even", 8..15 "odd" halves of the points 0..7, and so on): 8
+//   consecutive lanes read 64 contiguous bytes of one row -- the texture path takes that as well as rows of 16
+//   (17.2 cycles) -- and partners are 8 lanes apart inside one DPP row: the hand-over is row_ror:8, a DPP move again.
+// Measured on one box (tools/ab_libs.py), lbl kernel per 2 048-column launch / flattened repwvl kernel per step:
+//   Pair<0> 67.35 ms / 345.1 us,  Pair<1> 69.08 ms / 339.0 us (the swizzle's latency sits in the angle chain),
+//   Pair<2> 66.76 ms / 335.9 us: both kernels use Pair<2> (RCM_LBL_LAYOUT / RCM_RW_LAYOUT).
 #ifndef RCM_LBL_LAYOUT
-#define RCM_LBL_LAYOUT 0
+#define RCM_LBL_LAYOUT 2
 #endif
 #ifndef RCM_RW_LAYOUT
-#define RCM_RW_LAYOUT 1
+#define RCM_RW_LAYOUT 2
 #endif
 
 // v of the lane OFF lanes away (xor): DPP inside a row of 16 lanes, ds_swizzle / ds_bpermute across rows.
@@ -433,6 +436,35 @@ struct Pair<1> {  // rows of 16 lanes
       hi = __builtin_amdgcn_update_dpp(hi, hi, 0x128, 0xF, 0xF, true);
       v += __hiloint2double(hi, lo);
     }
+    if constexpr (BITS >= 5) v += __shfl_xor(v, 32, 64);
+    return v;
+  }
+};
+
+template <>
+struct Pair<2> {  // half-rows of 8 lanes alternate in parity; partners are 8 lanes apart IN THE SAME ROW of 16
+  static __device__ __forceinline__ int parity(int lane) { return (lane >> 3) & 1; }
+  static __device__ __forceinline__ int index(int lane) { return (lane & 7) | ((lane >> 4) << 3); }
+  static __device__ __forceinline__ int lane_of(int index, int parity) { return (index & 7) | (parity << 3) | ((index >> 3) << 4); }
+  static __device__ __forceinline__ double swap(double v) {  // row_ror:8 = xor 8 inside a row: one DPP move per half
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_update_dpp(lo, lo, 0x128, 0xF, 0xF, true);
+    hi = __builtin_amdgcn_update_dpp(hi, hi, 0x128, 0xF, 0xF, true);
+    return __hiloint2double(hi, lo);
+  }
+  // index bits 0..2 = lane bits 0..2 (two quad-permutes and a half-row mirror: after the quad levels every lane of a
+  // quad holds the quad's sum, so the mirror image 7-i is as good as i^4), bits 3, 4 = lane bits 4, 5
+  template <int BITS>
+  static __device__ __forceinline__ double sum(double v) {
+    if constexpr (BITS >= 1) v += lane_xor<1>(v);
+    if constexpr (BITS >= 2) v += lane_xor<2>(v);
+    if constexpr (BITS >= 3) {  // row_half_mirror
+      int lo = __double2loint(v), hi = __double2hiint(v);
+      lo = __builtin_amdgcn_update_dpp(lo, lo, 0x141, 0xF, 0xF, true);
+      hi = __builtin_amdgcn_update_dpp(hi, hi, 0x141, 0xF, 0xF, true);
+      v += __hiloint2double(hi, lo);
+    }
+    if constexpr (BITS >= 4) v += lane_xor<16>(v);
     if constexpr (BITS >= 5) v += __shfl_xor(v, 32, 64);
     return v;
   }

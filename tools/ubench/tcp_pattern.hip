@@ -5,6 +5,7 @@
 //   2 quad            row = (lane>>1)&1, col = (lane>>2)*2 + (lane&1) [A A B B ..]
 //   3 row16           row = (lane>>4)&1, col = (lane&15) + 16*(lane>>5)
 //   4 half-wave       row = lane>>5,     col = lane&31
+//   5 row8            row = (lane>>3)&1, col = (lane&7) + 8*(lane>>4)   (partner = lane^8: one DPP row_ror:8)
 // Every wave issues `iters` x 20 independent loads (like one layer of the repwvl optical-depth stage) and sums them.
 //   hipcc -O3 --offload-arch=gfx950 tools/ubench/tcp_pattern.hip -o /tmp/tcp_pattern && /tmp/tcp_pattern
 #include <hip/hip_runtime.h>
@@ -19,7 +20,8 @@ __global__ __launch_bounds__(256) void k(const double *tab, long ld, int nrows, 
   else if (PAT == 1) row = lane & 1, col = lane >> 1;
   else if (PAT == 2) row = (lane >> 1) & 1, col = (lane >> 2) * 2 + (lane & 1);
   else if (PAT == 3) row = (lane >> 4) & 1, col = (lane & 15) + 16 * (lane >> 5);
-  else row = lane >> 5, col = lane & 31;
+  else if (PAT == 4) row = lane >> 5, col = lane & 31;
+  else row = (lane >> 3) & 1, col = (lane & 7) + 8 * (lane >> 4);  // 5: half-rows of 8 lanes alternate
   const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
   double acc = 0.0;
   unsigned r0 = (unsigned)(wave * 7) % (unsigned)(nrows - 40);
@@ -67,14 +69,15 @@ int bench(long ld, int shift) {
   const double *tabs = tab + shift;
   printf("---- row length %ld doubles, column shift %d doubles\n", ld, shift);
   const int iters = 200, blocks = 256 * 3;  // 12 waves per CU
-  const char *names[5] = {"contiguous", "pair-interleave [ABAB]", "quad [AABB]", "row16", "half-wave"};
-  float ms[5];
+  const char *names[6] = {"contiguous", "pair-interleave [ABAB]", "quad [AABB]", "row16", "half-wave", "row8"};
+  float ms[6];
   ms[0] = run<0>(tabs, ld, nrows, iters, out, blocks);
   ms[1] = run<1>(tabs, ld, nrows, iters, out, blocks);
   ms[2] = run<2>(tabs, ld, nrows, iters, out, blocks);
   ms[3] = run<3>(tabs, ld, nrows, iters, out, blocks);
   ms[4] = run<4>(tabs, ld, nrows, iters, out, blocks);
-  for (int p = 0; p < 5; ++p) {
+  ms[5] = run<5>(tabs, ld, nrows, iters, out, blocks);
+  for (int p = 0; p < 6; ++p) {
     const double loads_per_cu = 12.0 * iters * 20;  // wave-level load instructions per CU
     printf("%-24s %8.3f ms  %6.1f ns per wave-load per CU (%5.1f cycles at 2.4 GHz)\n", names[p], ms[p],
            ms[p] * 1e6 / loads_per_cu, ms[p] * 1e6 / loads_per_cu * 2.4);
