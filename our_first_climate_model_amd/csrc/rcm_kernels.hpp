@@ -852,12 +852,16 @@ __device__ __forceinline__ void repwvl_bracket(const Dev &d, const double (&tp)[
   *xoff = (unsigned)((((size_t)layer * d.n_tpert + it) * d.n_species) * d.n_wvl * sizeof(double));
 }
 
-__device__ __forceinline__ void repwvl_bracket_store_pre(const Dev &d, int c, int l, const double (&tp)[kMaxTpert], double tr,
-                                                         double nd, double Tadj, double midT, double Tsfc) {
+// Start of an iteration, repwvl: lane l = layer l of column c stores the layer's bracket for the optical depths of
+// this iteration (temperature midT) and 1/T of the adjusted profile; lane NL stores 1/T_surface.
+__device__ __forceinline__ void repwvl_bracket_store(const Dev &d, int c, int l, double Tadj, double midT, double Tsfc) {
+  if (d.mode != MODE_REPWVL) return;
+  double tp[kMaxTpert];
+  load_tpert(d, tp);
   if (l < NL) {
     double wA, wB;
     unsigned xoff;
-    repwvl_bracket(d, tp, l, tr, nd, midT, &wA, &wB, &xoff);
+    repwvl_bracket(d, tp, l, d.tref_l[l], d.numDens[l], midT, &wA, &wB, &xoff);
     d.brk_w[((size_t)c * 2 + 0) * NL + l] = wA;
     d.brk_w[((size_t)c * 2 + 1) * NL + l] = wB;
     d.brk_off[(size_t)c * NL + l] = xoff;
@@ -865,15 +869,6 @@ __device__ __forceinline__ void repwvl_bracket_store_pre(const Dev &d, int c, in
   } else if (l == NL) {
     d.rT[(size_t)c * NLEV + NL] = 1.0 / Tsfc;
   }
-}
-
-// Start of an iteration, repwvl: lane l = layer l of column c stores the layer's bracket for the optical depths of
-// this iteration (temperature midT) and 1/T of the adjusted profile; lane NL stores 1/T_surface.
-__device__ __forceinline__ void repwvl_bracket_store(const Dev &d, int c, int l, double Tadj, double midT, double Tsfc) {
-  if (d.mode != MODE_REPWVL) return;
-  double tp[kMaxTpert];
-  load_tpert(d, tp);
-  repwvl_bracket_store_pre(d, c, l, tp, l < NL ? d.tref_l[l] : 0.0, l < NL ? d.numDens[l] : 0.0, Tadj, midT, Tsfc);
 }
 
 // Fills the LDS image of column `col`: per (parity, position) the temperature bracket of read_tau
@@ -1077,8 +1072,6 @@ __global__ __launch_bounds__(64 * WPB, RCM_PAIR_LB) void k_rt_repwvl_pair(Dev d)
 // ---------------------------------------------------------------------------------------------
 struct PostIn {  // what post_column reads from HBM for (column c, layer l): loaded by the caller up front, so that
   double T, conv, solar, Tprev, rel_hum, player, h2o_ref;  // the latencies overlap the sum of the partial records
-  double tref, numDens;   // repwvl: the layer's bracket constants
-  double tp[kMaxTpert];   // repwvl: the table's temperature perturbations
 };
 
 __device__ __forceinline__ PostIn post_load(const Dev &d, int c, int l, int next_pre) {
@@ -1093,13 +1086,8 @@ __device__ __forceinline__ PostIn post_load(const Dev &d, int c, int l, int next
       in.rel_hum = d.rel_hum[at];
       in.player = d.player[l];
       in.h2o_ref = d.mode == MODE_LBL ? d.h2o_ref[l] : 1.0;
-      if (d.mode == MODE_REPWVL) {
-        in.tref = d.tref_l[l];
-        in.numDens = d.numDens[l];
-      }
     }
   }
-  if (next_pre && d.mode == MODE_REPWVL) load_tpert(d, in.tp);
   return in;
 }
 
@@ -1174,7 +1162,7 @@ __device__ __forceinline__ void post_column(const Dev &d, int c, int l, const Po
   if (l == 0) d.resid[c] = r;
   if (l <= NL) {  // the next iteration's brackets; T_surface was formed by lane NL-1 above
     const double Tsfc = __shfl(Tn * conv, NL - 1, 64);
-    if (d.mode == MODE_REPWVL) repwvl_bracket_store_pre(d, c, l, in.tp, in.tref, in.numDens, Tadj, Tadj, Tsfc);
+    repwvl_bracket_store(d, c, l, Tadj, Tadj, Tsfc);
   }
 }
 
