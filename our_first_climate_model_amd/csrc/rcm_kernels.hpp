@@ -1237,29 +1237,39 @@ __global__ __launch_bounds__(64 * FWPB, RCM_FLAT_LB) void k_rt_repwvl_flat(Dev d
   return;
 #endif
   const int c_first = (int)(flat0 / nw), c_last = (int)(min(flat0 + 31, nflat - 1) / nw);
-  // The 42 sums of a record leave the wave in ONE store instruction (336 contiguous bytes from lanes 0..41), not in
-  // 21 instructions of two lanes each: a store instruction costs the texture path the same whatever its lane count,
-  // and 1.3 million of them per step were 45 us of the kernel (ablation builds).  The two lanes that hold the
-  // sums in the fixed order (pair 0 of either parity) put them in record order into the wave's staging row first.
-  const bool writer = lane == PairRw::lane_of(0, 0) || lane == PairRw::lane_of(0, 1);
-  double *E = &st[0][0];  // the staging columns are free after the angle loop
+  // Per column of the wave's 32 items: the 21 sums of either parity, in a fixed order.  Three DPP levels sum inside
+  // the half-rows of 8 lanes (Pair<2>: a half-row is one parity); the four half-row sums of a parity meet in the
+  // staging rows, where lane e (0..41) adds the four that make up record element e and stores it: ONE store
+  // instruction of 336 contiguous bytes per record (a store instruction costs the texture path the same whatever
+  // its lane count), and no butterfly level through the LDS crossbar.
+  static_assert(RCM_RW_LAYOUT == 2, "the reduction below assumes half-rows of 8 lanes");
+  double *S = &st[0][0];  // [21 values][8 half-rows]: the staging columns are free after the angle loop
+  // record element e = lane: E_down[e] (e <= 20) / E_up[e-21]; which parity holds it, and as which of its 21 values
+  // (value v: acc1[v] for v <= 10, acc2[v-11] above; even parity: acc1[j] = E_down[j], acc2[k] = E_up[k]; odd parity:
+  // acc1[j] = E_up[20-j], acc2[k] = E_down[20-k])
+  int ep = 0, ev = 0;
+  if (lane < PSTRIDE) {
+    const int m = lane - NLEV;
+    if (lane <= NH) ep = 0, ev = lane;
+    else if (lane <= NL) ep = 1, ev = NH + 1 + (NL - lane);
+    else if (m < NH) ep = 0, ev = NH + 1 + m;
+    else ep = 1, ev = NL - m;
+  }
   for (int c = c_first; c <= c_last; ++c) {
     const bool mine = col == c;
     const long seg0 = max((long)c * nw, flat0);
     const long slot = (seg0 - (long)c * nw + 31) / 32;
     double *out = d.partial + ((size_t)c * d.nchunk + slot) * PSTRIDE;  // E_down[21], E_up[21]
 #pragma unroll
-    for (int j = 0; j <= NH; ++j) {  // even lane: E_down[j]; odd lane: E_up[20-j]
-      const double v = PairRw::sum<5>(mine ? acc1[j] : 0.0);
-      if (writer) E[p ? NLEV + NL - j : j] = v;
-    }
-#pragma unroll
-    for (int k = 0; k < NH; ++k) {   // even lane: E_up[k]; odd lane: E_down[20-k]
-      const double v = PairRw::sum<5>(mine ? acc2[k] : 0.0);
-      if (writer) E[p ? NL - k : NLEV + k] = v;
+    for (int v = 0; v < NLEV; ++v) {
+      const double x = PairRw::sum<3>(mine ? (v <= NH ? acc1[v <= NH ? v : 0] : acc2[v > NH ? v - NH - 1 : 0]) : 0.0);
+      if ((lane & 7) == 0) S[v * 8 + (lane >> 3)] = x;  // lane >> 3 = 2 * (half-row of the parity) + parity
     }
     __builtin_amdgcn_wave_barrier();  // one wave: its LDS operations execute in program order
-    if (lane < PSTRIDE) out[lane] = E[lane];
+    if (lane < PSTRIDE) {
+      const double *q = S + ev * 8 + ep;
+      out[lane] = ((q[0] + q[2]) + q[4]) + q[6];
+    }
     __builtin_amdgcn_wave_barrier();
   }
   RCM_PT_STAMP(18);
