@@ -467,9 +467,7 @@ int rcm_create(int ncol, int nlayer, int nangle, int device, void *stream, rcm_e
   rc = rc ? rc : dev_alloc(h, (double **)&d.cloud_tau, (size_t)ncol);
   rc = rc ? rc : dev_alloc(h, (int **)&d.cloud_layer, (size_t)ncol);
   rc = rc ? rc : dev_alloc(h, &d.resid, (size_t)ncol);
-  rc = rc ? rc : dev_alloc(h, &d.brk_w, 2 * nT);
-  rc = rc ? rc : dev_alloc(h, &d.brk_off, nT);
-  rc = rc ? rc : dev_alloc(h, &d.rT, nE);
+
   rc = rc ? rc : dev_alloc(h, &d.Tprev, nT);
   rc = rc ? rc : dev_alloc(h, (double **)&d.player, (size_t)NL);
   rc = rc ? rc : dev_alloc(h, (double **)&d.conv, (size_t)NL);
@@ -684,6 +682,7 @@ int rcm_set_repwvl_tables(rcm_ensemble *h, int n_tpert, int n_species, int n_wvl
   rc = rc ? rc : dev_upload(h, (double **)&d.xsec, xt.data(), xt.size());
   rc = rc ? rc : dev_alloc(h, &h->d_xp, (size_t)NL * n_tpert * n_species * n_wvl);
   rc = rc ? rc : dev_alloc(h, &h->d_tref_l, (size_t)NL);
+  rc = rc ? rc : dev_alloc(h, (char **)&d.img, (size_t)h->ncol * sizeof(rcm::RepwvlPairLds));  // 3.8 KB per column
   d.xp = h->d_xp;
   d.tref_l = h->d_tref_l;
   h->t_ref.assign(t_ref, t_ref + n_p);

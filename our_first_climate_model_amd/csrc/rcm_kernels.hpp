@@ -99,11 +99,10 @@ struct Dev {
   const double *xsec, *t_ref, *t_pert, *delP, *numDens, *pnum, *lam5, *lkb;
   const double *xp;  // [layer][t][s][w]: xsec interpolated to the layer's mid pressure (host, with the grid)
   const double *tref_l;  // [layer]: t_ref[ip[layer]], the reference temperature of the layer's pressure bracket (host)
-  // repwvl, per column and layer, written at the start of every iteration (k_pre / post_column) for the flattened
-  // kernel's image build: the temperature bracket of read_tau as two weights and a table offset, and 1/T
-  double *brk_w;      // [ncol][2][NL]: numDens*(1-delT), numDens*delT
-  unsigned *brk_off;  // [ncol][NL]: byte offset of xp[l][it][0][0]
-  double *rT;         // [ncol][NL+1]: 1/Tlayer (adjusted), 1/T_surface
+  // repwvl, per column, written at the start of every iteration (k_pre / post_column, repwvl_image_store): the
+  // complete column image of the flattened kernel -- temperature brackets, interpolation coefficients with the mixing
+  // ratios folded in, T, 1/T, cloud -- which that kernel (2.3 blocks touch a column) only copies
+  void *img;          // [ncol] RepwvlPairLds: the column image the flattened kernel copies into LDS
   const double *rw_xc, *rw_sc;  // per wavelength: h*c/(lambda*kB) and pnum/lam5/1e9 (planck_mono_fast), host-formed
   const int *ip;
   int n_tpert, n_species, n_p, n_wvl;
@@ -852,22 +851,46 @@ __device__ __forceinline__ void repwvl_bracket(const Dev &d, const double (&tp)[
   *xoff = (unsigned)((((size_t)layer * d.n_tpert + it) * d.n_species) * d.n_wvl * sizeof(double));
 }
 
-// Start of an iteration, repwvl: lane l = layer l of column c stores the layer's bracket for the optical depths of
-// this iteration (temperature midT) and 1/T of the adjusted profile; lane NL stores 1/T_surface.
-__device__ __forceinline__ void repwvl_bracket_store(const Dev &d, int c, int l, double Tadj, double midT, double Tsfc) {
+// Start of an iteration, repwvl: a whole wave (lane l = layer l for l < NL) writes the image of column c for the
+// optical depths of this iteration -- brackets at the temperatures midT, coefficients numDens*(1-delT)*vmr and
+// numDens*delT*vmr, the adjusted temperatures and their reciprocals, T_surface, the cloud -- to d.img[c], in the layout
+// the flattened kernel keeps in LDS.  h2o = this iteration's H2O mixing ratio of layer l (it may have been written to
+// d.gas by this very wave a moment ago: it travels through LDS, not through HBM).  scr: 3*NL doubles of LDS owned by
+// the wave, free at this point.
+__device__ __forceinline__ void repwvl_image_store(const Dev &d, int c, int lane, double Tadj, double midT, double Tsfc,
+                                                   double h2o, double *scr) {
   if (d.mode != MODE_REPWVL) return;
+  RepwvlPairLds *g = reinterpret_cast<RepwvlPairLds *>(d.img) + c;
   double tp[kMaxTpert];
   load_tpert(d, tp);
-  if (l < NL) {
+  if (lane < NL) {
+    const int l = lane, q = l < NH ? 0 : 1, k = q ? NL - 1 - l : l;
     double wA, wB;
     unsigned xoff;
     repwvl_bracket(d, tp, l, d.tref_l[l], d.numDens[l], midT, &wA, &wB, &xoff);
-    d.brk_w[((size_t)c * 2 + 0) * NL + l] = wA;
-    d.brk_w[((size_t)c * 2 + 1) * NL + l] = wB;
-    d.brk_off[(size_t)c * NL + l] = xoff;
-    d.rT[(size_t)c * NLEV + l] = 1.0 / Tadj;
-  } else if (l == NL) {
-    d.rT[(size_t)c * NLEV + NL] = 1.0 / Tsfc;
+    scr[l] = wA, scr[NL + l] = wB, scr[2 * NL + l] = h2o;
+    g->T[q][k] = Tadj;
+    g->rT[q][k] = 1.0 / Tadj;
+    g->xoff[q][k] = xoff;
+    g->cloud[q][k] = (l == d.cloud_layer[c]) ? d.cloud_tau[c] : 0.0;
+  } else if (lane == NL) {
+    const double r = 1.0 / Tsfc;
+    g->T[0][NH] = Tsfc, g->T[1][NH] = Tsfc;
+    g->rT[0][NH] = r, g->rT[1][NH] = r;
+  }
+  __builtin_amdgcn_wave_barrier();  // one wave: its LDS operations execute in program order
+  constexpr int kPerLane = (2 * RCM_NSPEC_REPWVL * NH + 63) / 64;
+#pragma unroll
+  for (int m = 0; m < kPerLane; ++m) {
+    const int i = lane + 64 * m;
+    if (i < 2 * RCM_NSPEC_REPWVL * NH) {
+      const int q = i / (RCM_NSPEC_REPWVL * NH), r = i - q * (RCM_NSPEC_REPWVL * NH);
+      const int sp = r / NH, k = r - sp * NH;
+      const int layer = q ? NL - 1 - k : k;
+      const double vmr = sp == 0 ? scr[2 * NL + layer] : d.gas[((size_t)c * RCM_NSPEC_REPWVL + sp) * NL + layer];
+      g->cA[q][sp][k] = scr[layer] * vmr;  // :244 and :246 folded into the interpolation weights
+      g->cB[q][sp][k] = scr[NL + layer] * vmr;
+    }
   }
 }
 
@@ -925,44 +948,18 @@ __device__ __forceinline__ void repwvl_pair_image_from(const Dev &d, int col, in
   }
 }
 
-// The same image from the brackets k_pre / post_column stored for this iteration (repwvl_bracket_store): loads and
-// products only.  The flattened kernel builds every column's image 2.3 times per iteration (once per block that
-// touches it); the search and the divisions are done once per column.
-__device__ __forceinline__ void repwvl_pair_image_stored(const Dev &d, int col, int lane, RepwvlPairLds &s) {
-  constexpr int kPerLane = (2 * RCM_NSPEC_REPWVL * NH + 63) / 64;
-  double vmr[kPerLane], wa[kPerLane], wb[kPerLane];
+// The image as k_pre / post_column stored it for this iteration (repwvl_image_store): a copy, 16 bytes per lane and
+// load.  The flattened kernel brings every column's image into LDS 2.3 times per iteration (once per block that
+// touches the column); search, divisions and products are done once per column.
+__device__ __forceinline__ void repwvl_pair_image_copy(const Dev &d, int col, int lane, RepwvlPairLds &s) {
+  static_assert(sizeof(RepwvlPairLds) % 16 == 0, "copied in 16-byte pieces");
+  const double2 *src = reinterpret_cast<const double2 *>(reinterpret_cast<const RepwvlPairLds *>(d.img) + col);
+  double2 *dst = reinterpret_cast<double2 *>(&s);
+  constexpr int n16 = (int)(sizeof(RepwvlPairLds) / 16);
 #pragma unroll
-  for (int m = 0; m < kPerLane; ++m) {
-    const int i = min(lane + 64 * m, 2 * RCM_NSPEC_REPWVL * NH - 1);
-    const int q = i / (RCM_NSPEC_REPWVL * NH), r = i - q * (RCM_NSPEC_REPWVL * NH);
-    const int sp = r / NH, k = r - sp * NH;
-    const int layer = q ? NL - 1 - k : k;
-    vmr[m] = d.gas[((size_t)col * RCM_NSPEC_REPWVL + sp) * NL + layer];
-    wa[m] = d.brk_w[((size_t)col * 2 + 0) * NL + layer];
-    wb[m] = d.brk_w[((size_t)col * 2 + 1) * NL + layer];
-  }
-  if (lane < 2 * (NH + 1)) {
-    const int q = lane / (NH + 1), k = lane - q * (NH + 1);
-    const int layer = q ? NL - 1 - k : k;
-    if (k == NH) {
-      s.T[q][k] = d.Tsfc[col];
-      s.rT[q][k] = d.rT[(size_t)col * NLEV + NL];
-    } else {
-      s.T[q][k] = d.T[(size_t)col * NL + layer];
-      s.rT[q][k] = d.rT[(size_t)col * NLEV + layer];
-      s.xoff[q][k] = d.brk_off[(size_t)col * NL + layer];
-      s.cloud[q][k] = (layer == d.cloud_layer[col]) ? d.cloud_tau[col] : 0.0;
-    }
-  }
-#pragma unroll
-  for (int m = 0; m < kPerLane; ++m) {
+  for (int m = 0; m < (n16 + 63) / 64; ++m) {
     const int i = lane + 64 * m;
-    if (i < 2 * RCM_NSPEC_REPWVL * NH) {
-      const int q = i / (RCM_NSPEC_REPWVL * NH), r = i - q * (RCM_NSPEC_REPWVL * NH);
-      const int sp = r / NH, k = r - sp * NH;
-      s.cA[q][sp][k] = wa[m] * vmr[m];  // :244 and :246 folded into the interpolation weights
-      s.cB[q][sp][k] = wb[m] * vmr[m];
-    }
+    if (i < n16) dst[i] = src[i];
   }
 }
 
@@ -1139,7 +1136,7 @@ __device__ __forceinline__ void post_column(const Dev &d, int c, int l, const Po
     s_sorted[rank] = th;                 // sort(theta, greater), main.cpp:538
   }
   __builtin_amdgcn_wave_barrier();
-  double r = 0.0, Tadj = 0.0;
+  double r = 0.0, Tadj = 0.0, h2o = 0.0;
   if (on) {
     const double T = s_sorted[l] / conv;  // theta_to_t, main.cpp:131-139
     d.T[at] = T;
@@ -1148,6 +1145,7 @@ __device__ __forceinline__ void post_column(const Dev &d, int c, int l, const Po
     d.Ttau[at] = T;
     Tadj = T;
     const double vmr = in.rel_hum * magnus_dev(T) / in.player;  // main.cpp:285-286
+    h2o = vmr;
     double *gas = d.gas + (size_t)c * d.ngas * NL;
     if (d.mode == MODE_REPWVL)
       gas[0 * NL + l] = vmr;                    // H2O is read_tau's first species
@@ -1160,10 +1158,9 @@ __device__ __forceinline__ void post_column(const Dev &d, int c, int l, const Po
     r = (o > r || o != o) ? o : r;
   }
   if (l == 0) d.resid[c] = r;
-  if (l <= NL) {  // the next iteration's brackets; T_surface was formed by lane NL-1 above
-    const double Tsfc = __shfl(Tn * conv, NL - 1, 64);
-    repwvl_bracket_store(d, c, l, Tadj, Tadj, Tsfc);
-  }
+  // the next iteration's column image; T_surface was formed by lane NL-1 above; the scratch is free by now
+  __builtin_amdgcn_wave_barrier();
+  repwvl_image_store(d, c, l, Tadj, Tadj, __shfl(Tn * conv, NL - 1, 64), h2o, scr);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1211,7 +1208,7 @@ __global__ __launch_bounds__(64 * FWPB, RCM_FLAT_LB) void k_rt_repwvl_flat(Dev d
   for (int i = threadIdx.x; i < (int)((size_t)ncb * sizeof(RepwvlPairLds) / 8); i += blockDim.x)
     reinterpret_cast<double *>(imgs)[i] = 0.0;
 #else
-  for (int sl = wib; sl < ncb; sl += FWPB) repwvl_pair_image_stored(d, cb_first + sl, lane, imgs[sl]);
+  for (int sl = wib; sl < ncb; sl += FWPB) repwvl_pair_image_copy(d, cb_first + sl, lane, imgs[sl]);
 #endif
   __syncthreads();
   RCM_PT_STAMP(17);
@@ -1565,7 +1562,7 @@ __device__ __forceinline__ void adjust(const double *conv, double (&T)[NL], doub
 // the sorted array of a set of numbers is unique, so it is the array std::sort leaves.  A thread per
 // column (3 000 dependent instructions) took 10 us for ONE column and 18 us for 10 000.
 __global__ __launch_bounds__(64 * WPB) void k_pre(Dev d, int first) {
-  __shared__ double s_th[WPB][NL], s_sorted[WPB][NL];
+  __shared__ double s_th[WPB][NL], s_sorted[WPB][NL], s_img[WPB][3 * NL];
   const int lane = threadIdx.x & 63, wib = threadIdx.x >> 6;
   const int c = blockIdx.x * WPB + wib;
   const bool on = c < d.ncol && lane < NL;
@@ -1603,17 +1600,22 @@ __global__ __launch_bounds__(64 * WPB) void k_pre(Dev d, int first) {
     r = (o > r || o != o) ? o : r;
   }
   if (on && lane == 0) d.resid[c] = first ? 1e300 : r;
-  if (c < d.ncol && lane <= NL)  // this iteration's optical depths are interpolated at Ttau: T before (first) / after the adjustment
-    repwvl_bracket_store(d, c, lane, T, first ? Tpre : T, lane == NL ? d.Tsfc[c] : 0.0);
+  double h2o = 0.0;
   if (on && !first) {
     d.Ttau[at] = T;
     const double vmr = d.rel_hum[at] * magnus_dev(T) / d.player[lane];  // main.cpp:285-286
+    h2o = vmr;
     double *gas = d.gas + (size_t)c * d.ngas * NL;
     if (d.mode == MODE_REPWVL)
       gas[0 * NL + lane] = vmr;                    // H2O is read_tau's first species
     else
       gas[1 * NL + lane] = vmr / d.h2o_ref[lane];  // lbl: tau_H2O is linear in the mixing ratio
+  } else if (on && d.mode == MODE_REPWVL) {
+    h2o = d.gas[(size_t)c * d.ngas * NL + lane];   // first iteration: the initial mixing ratio, no feedback yet
   }
+  // this iteration's optical depths are interpolated at Ttau: T before (first) / after the adjustment
+  if (c < d.ncol)
+    repwvl_image_store(d, c, lane, T, first ? Tpre : T, lane == NL ? d.Tsfc[c] : 0.0, h2o, s_img[wib]);
 }
 
 // First stage of the chunk sum for FEW columns with MANY chunk records (one column x the full lbl
