@@ -98,6 +98,10 @@ __device__ __forceinline__ double planck_mono_fast(double xc, double sc, double 
 
 // ---------------------------------------------------------------------------------------------
 // Band-integrated Planck function: cplkavg.cpp:124-243 (libRadtran c_planck_func1).
+// PROVENANCE: cplkavg_dev below restates, branch for branch and with the reference's identifier names, the
+// algorithm of c_planck_func1 from libRadtran's cdisort.c (GPL; cplkavg.cpp:1-4 says where it was taken from).
+// Parity with the reference needs the same branches, series lengths and constants; it is the COLD path
+// (cplkavg_fast handles the narrow bands of the hot loop with arithmetic of its own).
 // Takes the wavenumber bounds (cplkavg.cpp:141-142 done by the caller, once per band) and
 // tpre = sigdpi * pow(t,4) (formed once per column-layer).  Same branches as the reference:
 // Simpson iteration to 1e-6 when the bounds are close (:155-182), else power / exponential
