@@ -21,6 +21,7 @@ import argparse
 import hashlib
 import json
 import os
+import re
 import sys
 import time
 
@@ -34,13 +35,20 @@ NOMINAL_CLOCK_HZ = 2.4e9
 N_SIMD = 256 * 4
 
 
-def kernel_source_id():
-    """Identifies the kernel build the committed instruction counts belong to: sha256 over the device sources.
+def kernel_source_id(read=None):
+    """Identifies the kernel build the committed instruction counts belong to: sha256 over the device sources
+    with comments and white space removed (a comment edit does not make the counts stale).
     tools/assemble_profiles.py stores it with the counters; a mismatch here means the counts are stale."""
     h = hashlib.sha256()
     for f in ("rcm_kernels.hpp", "rcm_device.hpp", "rcm_exp_coef.hpp"):
-        with open(os.path.join(ROOT, "our_first_climate_model_amd", "csrc", f), "rb") as fh:
-            h.update(fh.read())
+        if read is None:
+            with open(os.path.join(ROOT, "our_first_climate_model_amd", "csrc", f), "rb") as fh:
+                text = fh.read().decode()
+        else:
+            text = read(f)
+        text = re.sub(r"/\*.*?\*/", " ", text, flags=re.S)
+        text = re.sub(r"//[^\n]*", " ", text)
+        h.update("".join(text.split()).encode())
     return h.hexdigest()[:16]
 
 
