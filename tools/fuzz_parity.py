@@ -47,9 +47,9 @@ def run(ncases=120, seed=1, log=print, big=False):
             table = str(rng.choice(["Reduced10", "Reduced20", "Reduced100"]))
             ncol = int(rng.integers(1, 120))
             inp = H.make_inputs(pkg, "repwvl", ncol, table=table, perturb=bool(rng.random() < 0.8))
-            if rng.random() < 0.25:  # a few wavelengths only: below 8 the flattened kernel hands over to the chunked one
-                t = dict(inp["table"])
-                nw = int(rng.integers(1, min(13, t["n_wvl"]) + 1))
+            if rng.random() < 0.5:  # a run of the table's wavelengths: below 8 the flattened kernel hands over to the chunked
+                t = dict(inp["table"])  # one; odd counts put the column boundaries of the flattened list at odd lanes
+                nw = int(rng.integers(1, (min(13, t["n_wvl"]) if rng.random() < 0.5 else t["n_wvl"]) + 1))
                 w0 = int(rng.integers(0, t["n_wvl"] - nw + 1))
                 t["n_wvl"] = nw
                 t["wvl"], t["weight"] = t["wvl"][w0:w0 + nw].copy(), t["weight"][w0:w0 + nw].copy()
