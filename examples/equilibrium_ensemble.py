@@ -8,6 +8,9 @@ all-gather of (Tlayer[20], T_surface) ends the run.
     python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 \\
         examples/equilibrium_ensemble.py --ncol 100000 --tol 0.01 --max-steps 1500
 
+    python examples/equilibrium_ensemble.py --ncol 100000 --shard 3/8 --tol 0.01 --max-steps 1500   (rehearsal: the
+        block of rank 3 of 8 alone on one GPU, no collective; tools/eq100k_shards.sh runs all eight that way)
+
 Needs an MI355X per rank (the product has no CPU path).  Spectra are the seeded synthetic stand-in for the
 absent lbl.*.asc files (our_first_climate_model_amd.synth_lbl_tables)."""
 import argparse
@@ -28,6 +31,9 @@ def main():
     ap.add_argument("--max-steps", type=int, default=1000)
     ap.add_argument("--check-every", type=int, default=10)
     ap.add_argument("--progress", type=int, default=50, help="stderr line every so many iterations (0: none)")
+    ap.add_argument("--shard", default=None, metavar="R/W",
+                    help="rehearsal without a collective: integrate the block of rank R of W alone in this process")
+    ap.add_argument("--save-state", default=None, help="write the [columns][21] result of this process to a .npy file")
     a = ap.parse_args()
 
     import numpy as np
@@ -37,6 +43,10 @@ def main():
     from our_first_climate_model_amd.distributed import gather_state, run_to_equilibrium, shard_bounds
 
     rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
+    shard = None
+    if a.shard:
+        assert "RANK" not in os.environ, "--shard is the one-process rehearsal; under torchrun the ranks are the shards"
+        shard = tuple(int(x) for x in a.shard.split("/"))
     dev = int(os.environ.get("LOCAL_RANK", "0")) % max(torch.cuda.device_count(), 1)
     assert torch.cuda.is_available(), "needs the MI355X (no CPU fallback)"
     torch.cuda.set_device(dev)
@@ -44,7 +54,7 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=torch.device("cuda", dev))
 
-    lo, hi = shard_bounds(a.ncol, rank, world)
+    lo, hi = shard_bounds(a.ncol, *shard) if shard else shard_bounds(a.ncol, rank, world)
     atm, _ = rcm.atm_load(os.path.join(ROOT, "tests", "golden", "fpda.lbl.atm"))
     spec = rcm.perturbation_sweep(hi - lo, perturb_rh=True, perturb_ts=True, first=lo, total=a.ncol)
     cols = rcm.build_columns(atm, spec, "lbl")
@@ -63,15 +73,18 @@ def main():
     packed = torch.empty((hi - lo, 21), dtype=torch.float64, device="cuda")
     ens.pack_state(packed.data_ptr())
     ens.sync()
-    full = gather_state(packed, a.ncol, world, dist)
+    full = packed if shard else gather_state(packed, a.ncol, world, dist)
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
+    if a.save_state and rank == 0:
+        np.save(a.save_state, full.cpu().numpy())
     if rank == 0:
         ts = full[:, 20].cpu().numpy()
+        what = (f"columns {lo}..{hi - 1} (rank {shard[0]} of {shard[1]}, alone) of {a.ncol}" if shard else f"{a.ncol} columns")
         print(json.dumps({
-            "workload": f"{a.ncol} columns x {a.nodes - 1} lbl bands to equilibrium on {world} GPU(s)",
+            "workload": f"{what} x {a.nodes - 1} lbl bands to equilibrium on {world} GPU(s)",
             "steps": steps, "converged": bool(resid <= a.tol), "residual_K_per_step": resid, "tol_K": a.tol,
-            "seconds": elapsed, "column_timesteps_per_sec": a.ncol * steps / elapsed,
+            "seconds": elapsed, "column_timesteps_per_sec": (hi - lo if shard else a.ncol) * steps / elapsed,
             "T_surface_K": {"min": float(ts.min()), "median": float(np.median(ts)), "max": float(ts.max())},
             "all_finite": bool(torch.isfinite(full).all())}))
     if dist.is_initialized():
