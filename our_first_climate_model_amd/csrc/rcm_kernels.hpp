@@ -1170,10 +1170,12 @@ __device__ __forceinline__ void post_column(const Dev &d, int c, int l, const Po
 // work comes in 31 250 equal pieces for 10 000 x 100 (whole-column ownership leaves the last third of the run
 // to a partly empty chip, measured with k_step_repwvl).  What a wave does besides its one pass is kept small:
 //  * the column images are shared by the block: its 4 waves cover 128 consecutive items = at most 127/n_wvl + 2
-//    columns, one image each, built by the 4 waves in parallel (before: every wave built its own two);
-//  * the per-column sums are MASKED BUTTERFLIES over the lanes (a lane contributes its sums to the column its
-//    item belongs to and zero to the others), not serial loops through LDS;
-//  * 30.5 KB of LDS per block and <= 128 VGPRs: 4 waves per SIMD.
+//    columns, one image each, COPIED from HBM by the 4 waves in parallel (k_pre / k_post_wave store every column's
+//    image once per iteration, repwvl_image_store; before: every wave built its own two);
+//  * the per-column sums are masked (a lane contributes its sums to the column its item belongs to and zero to the
+//    others): three DPP levels inside the half-rows of 8 lanes, then the four half-row sums of a parity meet in the
+//    staging rows and one lane per output adds them -- not serial loops through LDS, no butterfly through ds_swizzle;
+//  * 34 KB of LDS per block (Reduced100: 3 images + 4 staging areas) and <= 128 VGPRs: 4 waves per SIMD.
 // A column's partial record goes to slot ceil((first item of the segment - first item of the column)/32), so
 // records never collide and the slots a column never uses stay zero (the buffer is zeroed once).
 // d.nchunk = number of slots.
@@ -1226,7 +1228,7 @@ __global__ __launch_bounds__(64 * FWPB, RCM_FLAT_LB) void k_rt_repwvl_flat(Dev d
   }
   if (flat0 >= nflat) return;  // (whole wave)
 
-  // ---- segmented reduction: one masked butterfly per column of the wave's 32 items (fixed order)
+  // ---- segmented reduction: per column of the wave's 32 items, masked, in a fixed order
   // even lane: acc1[j] = E_down[j] (j = 0..10), acc2[k] = E_up[k] (k = 0..9)
   // odd lane:  acc1[j] = E_up[20-j],           acc2[k] = E_down[20-k]
 #ifdef RCM_DBG_NOREDUCE  // ablation builds only
