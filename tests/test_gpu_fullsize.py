@@ -361,3 +361,58 @@ def test_rcm_gather_one_rank_over_rccl(pkg):
     finally:
         rccl.ncclCommDestroy.argtypes = [C.c_void_p]
         rccl.ncclCommDestroy(comm)
+
+
+def test_two_handles_on_two_streams_equal_one_handle(pkg):
+    """Columns never interact, so an ensemble may be cut into handles that run concurrently on their own HIP streams
+    (what --devices does across GPUs, here on one): bit-identical to the same columns in one handle when the cut
+    keeps the spectral chunking (repwvl: the flattened list restarts at the cut, so the wave boundaries inside the
+    second part move: last bits only)."""
+    import torch
+    ncol, steps = 600, 7
+    for mode, kw in (("repwvl", dict(table="Reduced100")), ("lbl", dict(n_nodes=2049, atm="fpda.lbl.atm"))):
+        inp = H.make_inputs(pkg, mode, ncol, **kw)
+        one = H.gpu_ensemble(pkg, inp)
+        one.step(steps)
+        want = one.get_state()
+        streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+        cut = 257
+        parts = [pkg.configure(pkg.Ensemble(len(idx), stream=s.cuda_stream), _columns(inp, idx))
+                 for s, idx in zip(streams, (np.arange(0, cut), np.arange(cut, ncol)))]
+        if mode == "lbl":
+            for p in parts:
+                p.set_spectral_chunks(one.get_spectral_chunks())
+        for p in parts:  # both enqueue before either is waited for
+            p.step(steps)
+        got = [p.get_state() for p in parts]
+        for k in ("Tlayer", "T_surface", "timestep"):
+            both = np.concatenate([g[k] for g in got])
+            if mode == "lbl":
+                assert np.array_equal(both, want[k]), (mode, k)
+            else:
+                assert H.max_abs(both, want[k]) <= 1e-10 * max(1.0, float(np.max(np.abs(want[k])))), (mode, k)
+        for p in parts:
+            p.close()
+        one.close()
+
+
+def test_handles_give_their_device_memory_back(pkg):
+    """create -> tables -> columns -> step -> destroy, twenty times per path: the free device memory ends where it began
+    (rcm_destroy frees every buffer of the handle, the partial records and the column images included)."""
+    import torch
+    inputs = [H.make_inputs(pkg, "repwvl", 300, table="Reduced100"),
+              H.make_inputs(pkg, "lbl", 300, n_nodes=4097, atm="fpda.lbl.atm")]
+    for inp in inputs:  # once unmeasured: the runtime's own first-use allocations (kernel code objects, streams)
+        g = H.gpu_ensemble(pkg, inp)
+        g.step(1), g.sync(), g.close()
+    torch.cuda.synchronize()
+    free0, _ = torch.cuda.mem_get_info()
+    for _ in range(20):
+        for inp in inputs:
+            g = H.gpu_ensemble(pkg, inp)
+            g.step(2)
+            g.get_fluxes()
+            g.close()
+    torch.cuda.synchronize()
+    free1, _ = torch.cuda.mem_get_info()
+    assert free0 - free1 <= 8 << 20, f"{(free0 - free1) / 2**20:.1f} MiB of device memory did not come back"

@@ -27,7 +27,7 @@ def run(ncases=120, seed=1, log=print, big=False):
     rng = np.random.default_rng(seed)
     olib = ol.load()
     worst = dict(flux=0.0, T=0.0, tau=0.0)
-    bad = 0
+    bad = flips = 0
     t_start = time.time()
     for case in range(ncases):
         mode = "lbl" if rng.random() < 0.6 else "repwvl"
@@ -86,15 +86,19 @@ def run(ncases=120, seed=1, log=print, big=False):
         # ... and the optical depths as the production kernels form them (clamped to [-10, 1e7] there)
         tp, tc = g.get_tau_production(col), np.clip(to, -10.0, 1e7)
         e_tau = max(e_tau, float(np.max(np.abs(tp - tc) / np.maximum(np.abs(tc), 1e-300))))
+        # `time` is a float sum of double steps (main.cpp:359,581): a step that differs in its last bits can flip ONE float
+        # rounding, so equality is the rule (3 exceptions in 30 000 cases) and 2 ulp of float per step the requirement
         same_time = bool(np.array_equal(sg["time_h"], so["time_h"]))
-        ok = e_flux <= FLUX_TOL and e_T <= T_TOL and e_tau <= TAU_RTOL and same_time
+        near_time = bool(np.allclose(sg["time_h"], so["time_h"], rtol=2.4e-7 * (steps + split), atol=0.0))
+        flips += not same_time
+        ok = e_flux <= FLUX_TOL and e_T <= T_TOL and e_tau <= TAU_RTOL and near_time
         bad += not ok
         worst["flux"], worst["T"], worst["tau"] = max(worst["flux"], e_flux), max(worst["T"], e_T), max(worst["tau"], e_tau)
         log(f"{case:4d} {mode:6s} ncol={ncol:4d} nspec={nspec:5d} nangle={nangle:2d} chunks={chunks or 'auto':>5} "
             f"used={g.get_spectral_chunks():4d} cloud=({inp['cloud_layer']:2d},{inp['cloud_tau']:4.1f}){'*' if percol else ' '} steps={steps}{'+1' if split else '  '} "
-            f"dFlux={e_flux:.2e} dT={e_T:.2e} dtau={e_tau:.1e} time={'==' if same_time else '!='} {'ok' if ok else 'FAIL'}")
+            f"dFlux={e_flux:.2e} dT={e_T:.2e} dtau={e_tau:.1e} time={'==' if same_time else ('~=' if near_time else '!=')} {'ok' if ok else 'FAIL'}")
         g.close()
-    log(f"{ncases} cases in {time.time() - t_start:.0f} s: {bad} outside tolerance; worst dFlux {worst['flux']:.2e} W/m^2, "
+    log(f"{ncases} cases in {time.time() - t_start:.0f} s: {bad} outside tolerance, {flips} with a float `time` one rounding apart; worst dFlux {worst['flux']:.2e} W/m^2, "
         f"dT {worst['T']:.2e} K, dtau {worst['tau']:.1e} (relative)")
     return bad, worst
 
