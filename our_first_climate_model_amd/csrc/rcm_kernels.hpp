@@ -53,6 +53,29 @@ constexpr int WPB = 4;       // waves per block = columns per block (one per SIM
 #ifndef RCM_RW_PLK_UNROLL
 #define RCM_RW_PLK_UNROLL 1  // monochromatic Planck evaluations in flight in the repwvl lane-pair kernels
 #endif
+// Wave priority: the phases around the angle loop (column images, optical depths, Planck, reduction) are short and
+// latency-bound; at a higher priority than the angle loops of the other waves of the SIMD they finish sooner.
+#ifndef RCM_PRIO
+#define RCM_PRIO 1
+#endif
+#if RCM_PRIO
+// (Not the builtin and not `asm volatile`: either counts as a store to anything, and the kernel's scalar loads then
+// become vector loads with a full wait each.  A plain asm tied to a value the next phase needs stays where it is put.)
+#ifndef RCM_PRIO_A
+#define RCM_PRIO_A 3  // before the angle loop
+#define RCM_PRIO_B 0  // in it
+#define RCM_PRIO_C 3  // after it
+#endif
+#define RCM_STR2(x) #x
+#define RCM_STR(x) RCM_STR2(x)
+#define RCM_PRIO_START(x) asm("s_setprio " RCM_STR(RCM_PRIO_A) : "+v"(x))
+#define RCM_PRIO_LO(x) asm("s_setprio " RCM_STR(RCM_PRIO_B) : "+v"(x))
+#define RCM_PRIO_HI(x) asm("s_setprio " RCM_STR(RCM_PRIO_C) : "+v"(x))
+#else
+#define RCM_PRIO_START(x) ((void)0)
+#define RCM_PRIO_HI(x) ((void)0)
+#define RCM_PRIO_LO(x) ((void)0)
+#endif
 #ifndef RCM_SWEEP_DIFF
 #define RCM_SWEEP_DIFF 1  // recurrences of the lane-pair kernels in difference form (2 FMAs per crossing and angle);
 #endif                    // 0: the emission form L = t*L + (1-t)*B (2.5), kept for A/B runs
@@ -1025,7 +1048,10 @@ __device__ __forceinline__ void repwvl_pair_point(const Dev &d, const RepwvlPair
 #pragma unroll
   for (int k = 0; k < NH; ++k) acc1[k] += tau[k] * B[k] + Linit, acc2[k] += tau[k];
 #else
-  pair_all_angles<PairRw, CUBE>(d, tau, B, Linit, st, lane, acc1, acc2);
+  double Lin = Linit;
+  RCM_PRIO_LO(Lin);
+  pair_all_angles<PairRw, CUBE>(d, tau, B, Lin, st, lane, acc1, acc2);
+  RCM_PRIO_HI(acc1[0]);
 #endif
   RCM_PT_STAMP(23);
 }
@@ -1190,7 +1216,8 @@ constexpr int FWPB = RCM_FLAT_WPB;
 template <int CUBE>
 __global__ __launch_bounds__(64 * FWPB, RCM_FLAT_LB) void k_rt_repwvl_flat(Dev d, int maxc) {
   extern __shared__ __align__(16) unsigned char s_dyn[];
-  const int lane = threadIdx.x & 63;
+  int lane = threadIdx.x & 63;
+  RCM_PRIO_START(lane);
   const int wib = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   RepwvlPairLds *imgs = reinterpret_cast<RepwvlPairLds *>(s_dyn);  // the block's columns
   double(*st)[64] = reinterpret_cast<double(*)[64]>(s_dyn + (size_t)maxc * sizeof(RepwvlPairLds) +
