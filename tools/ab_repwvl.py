@@ -29,7 +29,9 @@ for name, L in libs.items():
         g = H.gpu_ensemble(pkg, inp, library=L)
         g.set_step_fusion(fusion)
         ens[(name, cname)] = (g, lpc)
+import time
 times = {k: [] for k in ens}
+walls = {k: [] for k in ens}
 for r in range(rounds + 1):
     for k, (g, lpc) in ens.items():
         if lpc:
@@ -39,8 +41,16 @@ for r in range(rounds + 1):
         g.set_rt_timing(True)
         g.step(steps)
         ms, n = g.get_rt_timing()
+        g.set_rt_timing(False)  # the whole step without the timing events
+        g.sync()
+        t0 = time.perf_counter()
+        g.step(steps)
+        g.sync()
+        wall = (time.perf_counter() - t0) / steps
         if r:
             times[k].append(ms / steps)
+            walls[k].append(wall * 1e3)
 for k, t in times.items():
     t = np.array(t)
-    print(f"{k[0]:10s} {k[1]:8s} kernel median {np.median(t) * 1e3:7.1f} us/step (min {t.min() * 1e3:7.1f})", flush=True)
+    print(f"{k[0]:10s} {k[1]:8s} kernel median {np.median(t) * 1e3:7.1f} us/step (min {t.min() * 1e3:7.1f})   "
+          f"whole step median {np.median(walls[k]) * 1e3:7.1f} us (min {min(walls[k]) * 1e3:7.1f})", flush=True)
