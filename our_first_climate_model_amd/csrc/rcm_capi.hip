@@ -15,6 +15,9 @@
 #include "rcm_internal.hpp"
 #include "rcm_kernels.hpp"
 
+#ifndef RCM_MERGE_SHARED
+#define RCM_MERGE_SHARED 1  // repwvl: species with one profile for all columns share a merged table row set
+#endif
 #ifndef RCM_GEN15
 #define RCM_GEN15 1  // root pairs 3m / 5m from one exponential (0: every root its own)
 #endif
@@ -57,6 +60,8 @@ struct rcm_ensemble {
   double *d_xp = nullptr;      // [layer][t][s][w]: xsec interpolated to the layer's mid pressure (derive_repwvl_layers)
   double *d_tref_l = nullptr;  // [layer]: t_ref[ip[layer]]
   std::vector<double> t_ref;   // host copy
+  std::vector<double> shared_vmr;  // [9][NL]: the profiles of the species merged into d.merged_slot (rcm_set_columns)
+  unsigned shared_set = 0;         // which species those are
   int *d_ip = nullptr;
   double *d_delP = nullptr, *d_numDens = nullptr;
   // timing
@@ -133,6 +138,21 @@ int derive_repwvl_layers(rcm_ensemble *h) {
         double *o = &xp[((size_t)l * rows + r) * nw];
         for (size_t w = 0; w < nw; ++w) o[w] = std::fma(delP[l], x1[w] - x0[w], x0[w]);
       }
+    // species with one mixing-ratio profile for all columns (rcm_set_columns): their weighted sum takes the row set of
+    // the first of them; the others' rows stay as they are and are not visited (Dev::prod_mask)
+    if (d.merged_slot >= 0)
+      for (int l = 0; l < NL; ++l)
+        for (int t = 0; t < d.n_tpert; ++t) {
+          double *slot = &xp[(((size_t)l * d.n_tpert + t) * d.n_species + d.merged_slot) * nw];
+          std::vector<double> sum(nw, 0.0);
+          for (int sp = 0; sp < d.n_species; ++sp)
+            if ((h->shared_set >> sp) & 1u) {
+              const double v = h->shared_vmr[(size_t)sp * NL + l];
+              const double *x = &xp[(((size_t)l * d.n_tpert + t) * d.n_species + sp) * nw];
+              for (size_t w = 0; w < nw; ++w) sum[w] = std::fma(v, x[w], sum[w]);
+            }
+          std::copy(sum.begin(), sum.end(), slot);
+        }
     HIPCK(hipMemcpyAsync(h->d_xp, xp.data(), xp.size() * sizeof(double), hipMemcpyHostToDevice, h->stream));
     HIPCK(hipStreamSynchronize(h->stream));  // xp goes out of scope
   }
@@ -143,6 +163,43 @@ int derive_repwvl_layers(rcm_ensemble *h) {
   HIPCK(hipMemcpyAsync(h->d_delP, delP.data(), NL * sizeof(double), hipMemcpyHostToDevice, h->stream));
   HIPCK(hipMemcpyAsync(h->d_numDens, numDens.data(), NL * sizeof(double), hipMemcpyHostToDevice, h->stream));
   HIPCK(hipStreamSynchronize(h->stream));
+  return RCM_OK;
+}
+
+// repwvl: which species the optical-depth stages visit, from the mixing ratios [ncol][9][NL] (rcm_set_columns, and
+// rcm_checkpoint_load so that a resumed run forms its optical depths exactly as the run that wrote the checkpoint).
+int classify_species(rcm_ensemble *h, const double *gas) {
+  Dev &d = h->d;
+  // species whose mixing ratio is 0 everywhere add exactly +0
+  unsigned mask = 0;
+  for (int c = 0; c < h->ncol; ++c)
+    for (int s = 0; s < RCM_NSPEC_REPWVL; ++s)
+      for (int l = 0; l < NL; ++l)
+        if (gas[((size_t)c * RCM_NSPEC_REPWVL + s) * NL + l] != 0.0) mask |= 1u << s;
+  d.species_mask = mask | 1u;  // H2O always: the feedback rewrites it
+  // species (other than H2O) whose profile is the same in every column: one merged row set for all of them
+  unsigned same = d.species_mask & ~1u;
+  for (int s = 1; s < RCM_NSPEC_REPWVL; ++s)
+    for (int c = 1; c < h->ncol && ((same >> s) & 1u); ++c)
+      if (std::memcmp(&gas[((size_t)c * RCM_NSPEC_REPWVL + s) * NL], &gas[(size_t)s * NL], NL * sizeof(double)) != 0)
+        same &= ~(1u << s);
+  const unsigned old_set = h->shared_set;
+  const std::vector<double> old_vmr = h->shared_vmr;
+  if (RCM_MERGE_SHARED && __builtin_popcount(same) >= 2) {
+    h->shared_set = same;
+    h->shared_vmr.assign(gas, gas + (size_t)RCM_NSPEC_REPWVL * NL);  // column 0 = every column, for these species
+    d.merged_slot = __builtin_ctz(same);
+    d.prod_mask = (d.species_mask & ~same) | (1u << d.merged_slot);
+  } else {
+    h->shared_set = 0;
+    d.merged_slot = -1;
+    d.prod_mask = d.species_mask;
+  }
+  bool changed = old_set != h->shared_set;
+  for (int s = 0; !changed && s < RCM_NSPEC_REPWVL; ++s)
+    if ((h->shared_set >> s) & 1u)
+      changed = std::memcmp(&old_vmr[(size_t)s * NL], &h->shared_vmr[(size_t)s * NL], NL * sizeof(double)) != 0;
+  if (changed) return derive_repwvl_layers(h);  // (a no-op until the grid is known; rcm_set_grid derives then)
   return RCM_OK;
 }
 
@@ -449,6 +506,7 @@ int rcm_create(int ncol, int nlayer, int nangle, int device, void *stream, rcm_e
   }
   Dev &d = h->d;
   d.ncol = ncol, d.nangle = nangle, d.mode = rcm::MODE_NONE;
+  d.merged_slot = -1;
   d.dp = 1000.0 / (double)nlayer;  // main.cpp:355
   d.sigdpi = 5.67032E-8 / M_PI;    // cplkavg.cpp:121,134
   const size_t nT = (size_t)ncol * NL, nE = (size_t)ncol * NLEV;
@@ -700,7 +758,9 @@ int rcm_set_repwvl_tables(rcm_ensemble *h, int n_tpert, int n_species, int n_wvl
   d.nspec = n_wvl;
   d.ngas = RCM_NSPEC_REPWVL;
   d.mode = h->mode = rcm::MODE_REPWVL;
-  d.species_mask = 0x1ff;
+  d.species_mask = d.prod_mask = 0x1ff;
+  d.merged_slot = -1;
+  h->shared_set = 0;
   return derive_repwvl_layers(h);
 }
 
@@ -762,14 +822,8 @@ int rcm_set_columns(rcm_ensemble *h, const double *Tlayer0, const double *T_surf
   const size_t nT = (size_t)h->ncol * NL, nG = nT * d.ngas;
   if (!d.gas)
     if (int rc = dev_alloc(h, &d.gas, nG)) return rc;
-  if (h->mode == rcm::MODE_REPWVL) {  // species whose mixing ratio is 0 everywhere add exactly +0
-    unsigned mask = 0;
-    for (int c = 0; c < h->ncol; ++c)
-      for (int s = 0; s < RCM_NSPEC_REPWVL; ++s)
-        for (int l = 0; l < NL; ++l)
-          if (gas[((size_t)c * RCM_NSPEC_REPWVL + s) * NL + l] != 0.0) mask |= 1u << s;
-    d.species_mask = mask | 1u;  // H2O always: the feedback rewrites it
-  }
+  if (h->mode == rcm::MODE_REPWVL)
+    if (int rc = classify_species(h, gas)) return rc;
   HIPCK(hipMemcpyAsync(d.T, Tlayer0, nT * sizeof(double), hipMemcpyHostToDevice, h->stream));
   HIPCK(hipMemcpyAsync(d.Ttau, Tlayer0, nT * sizeof(double), hipMemcpyHostToDevice, h->stream));
   HIPCK(hipMemcpyAsync(d.Tsfc, T_surface0, h->ncol * sizeof(double), hipMemcpyHostToDevice, h->stream));
@@ -1061,11 +1115,15 @@ int rcm_checkpoint_load(rcm_ensemble *h, const char *path) {
       std::fclose(f);
       return fail(RCM_ERR_HIP, std::string("rcm_checkpoint_load: ") + hipGetErrorString(e));
     }
+    if (fld.dev == (void *)h->d.gas && h->mode == rcm::MODE_REPWVL)  // the species pattern of the run that saved it
+      if (int rc = classify_species(h, reinterpret_cast<const double *>(buf.data()))) {
+        std::fclose(f);
+        return rc;
+      }
   }
   std::fclose(f);
   h->step_index = hdr[4];
   h->have_columns = true;
-  if (h->mode == rcm::MODE_REPWVL) h->d.species_mask = 0x1ff;  // unknown zero pattern: interpolate all nine
   return RCM_OK;
 }
 

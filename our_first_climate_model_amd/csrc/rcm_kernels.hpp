@@ -48,10 +48,11 @@ constexpr int WPB = 4;       // waves per block = columns per block (one per SIM
 #define RCM_PLK_UNROLL 1  // independent band-Planck evaluations in flight
 #endif
 #ifndef RCM_RW_TAU_UNROLL
-#define RCM_RW_TAU_UNROLL 1  // layers of the repwvl optical-depth stage in flight (20 table loads each)
+#define RCM_RW_TAU_UNROLL 10  // layers of the repwvl optical-depth stage in flight (10 table loads each); with the
+                              // wave priorities 10 beats 1 by 1.2 % (it made no difference before them)
 #endif
 #ifndef RCM_RW_PLK_UNROLL
-#define RCM_RW_PLK_UNROLL 1  // monochromatic Planck evaluations in flight in the repwvl lane-pair kernels
+#define RCM_RW_PLK_UNROLL 11  // monochromatic Planck evaluations in flight in the repwvl lane-pair kernels (all: another 0.7 %)
 #endif
 // Wave priority: the phases around the angle loop (column images, optical depths, Planck, reduction) are short and
 // latency-bound; at a higher priority than the angle loops of the other waves of the SIMD they finish sooner.
@@ -129,7 +130,13 @@ struct Dev {
   const double *rw_xc, *rw_sc;  // per wavelength: h*c/(lambda*kB) and pnum/lam5/1e9 (planck_mono_fast), host-formed
   const int *ip;
   int n_tpert, n_species, n_p, n_wvl;
-  unsigned species_mask;
+  unsigned species_mask;  // species with a non-zero mixing ratio somewhere (the reference-form getter and kernels)
+  // Production kernels: species whose mixing-ratio profile is THE SAME IN EVERY COLUMN (O3, N2O, CH4 in a CO2 sweep) are
+  // summed into one table row set on the host, xp[l][t][merged_slot][w] = sum_s vmr_s[l] * xp[l][t][s][w]
+  // (derive_repwvl_layers): the kernels then load 2 corners for H2O, for every species that does vary, and for the
+  // merged one (coefficient: the interpolation weight alone), 60 table loads per point instead of 100.
+  unsigned prod_mask;     // species the production optical-depth stage visits
+  int merged_slot;        // -1: nothing merged
 };
 
 #ifdef RCM_WITH_VARIANTS  // one-lane-per-point reference variants: test-side library only (tests/_variants)
@@ -910,7 +917,8 @@ __device__ __forceinline__ void repwvl_image_store(const Dev &d, int c, int lane
       const int q = i / (RCM_NSPEC_REPWVL * NH), r = i - q * (RCM_NSPEC_REPWVL * NH);
       const int sp = r / NH, k = r - sp * NH;
       const int layer = q ? NL - 1 - k : k;
-      const double vmr = sp == 0 ? scr[2 * NL + layer] : d.gas[((size_t)c * RCM_NSPEC_REPWVL + sp) * NL + layer];
+      const double vmr = sp == 0 ? scr[2 * NL + layer]
+                         : sp == d.merged_slot ? 1.0 : d.gas[((size_t)c * RCM_NSPEC_REPWVL + sp) * NL + layer];
       g->cA[q][sp][k] = scr[layer] * vmr;  // :244 and :246 folded into the interpolation weights
       g->cB[q][sp][k] = scr[NL + layer] * vmr;
     }
@@ -937,7 +945,8 @@ __device__ __forceinline__ void repwvl_pair_image_from(const Dev &d, int col, in
     const int sp = r / NH, k = r - sp * NH;
     const int layer = q ? NL - 1 - k : k;
     vmr[m] = (i < 2 * RCM_NSPEC_REPWVL * NH)
-                 ? (sp == 0 ? h2o[layer] : d.gas[((size_t)col * RCM_NSPEC_REPWVL + sp) * NL + layer])
+                 ? (sp == 0 ? h2o[layer]
+                    : sp == d.merged_slot ? 1.0 : d.gas[((size_t)col * RCM_NSPEC_REPWVL + sp) * NL + layer])
                  : 0.0;
   }
   double tp[kMaxTpert];
@@ -1011,7 +1020,7 @@ __device__ __forceinline__ void repwvl_pair_tau(const Dev &d, const RepwvlPairLd
     double a = 0.0;
 #pragma unroll
     for (int sp = 0; sp < RCM_NSPEC_REPWVL; ++sp) {
-      if (!((d.species_mask >> sp) & 1u)) continue;  // vmr == 0 everywhere: the term is +0
+      if (!((d.prod_mask >> sp) & 1u)) continue;  // vmr == 0 everywhere (the term is +0), or merged into another row
       const unsigned v = vo + (unsigned)sp * ld8;
       a = fma(s.cA[p][sp][k], *(const double *)(bA + v), fma(s.cB[p][sp][k], *(const double *)(bB + v), a));
     }

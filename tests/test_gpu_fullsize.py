@@ -416,3 +416,40 @@ def test_handles_give_their_device_memory_back(pkg):
     torch.cuda.synchronize()
     free1, _ = torch.cuda.mem_get_info()
     assert free0 - free1 <= 8 << 20, f"{(free0 - free1) / 2**20:.1f} MiB of device memory did not come back"
+
+
+@pytest.mark.parametrize("case", ["all_shared", "some_vary", "only_one_shared", "all_vary", "new_columns"])
+def test_species_with_one_profile_for_all_columns_are_merged_correctly(pkg, olib, case):
+    """The production optical-depth stage sums the species whose mixing-ratio profile is the same in every column into
+    one table row set (Dev::merged_slot, derive_repwvl_layers); which species those are depends on the ensemble.  Whatever
+    the pattern, optical depths (<= 1e-12 relative) and fluxes equal the oracle's, which knows nothing of merging."""
+    rng = np.random.default_rng(7)
+    ncol = 1 if case == "all_shared" else 12
+    inp = H.make_inputs(pkg, "repwvl", ncol, table="Reduced20")
+    gas = inp["cols"]["gas"]  # [ncol][9][20]; H2O 0, CO2 1, O3 2, N2O 3, CO 4, CH4 5, O2 6, HNO3 7, N2 8
+    if case == "some_vary":        # N2O and CO differ from column to column: merged = {O3, CH4}
+        gas[:, 3] *= rng.uniform(0.5, 2.0, (ncol, 1))
+        gas[:, 4] = 1e-7 * rng.uniform(0.5, 2.0, (ncol, 20))
+    elif case == "only_one_shared":  # everything but CH4 varies: nothing to merge
+        for s in (2, 3):
+            gas[:, s] *= rng.uniform(0.5, 2.0, (ncol, 1))
+    elif case == "all_vary":
+        for s in (2, 3, 5):
+            gas[:, s] *= rng.uniform(0.5, 2.0, (ncol, 20))
+    g, o = H.gpu_ensemble(pkg, inp), H.oracle_ensemble(olib, inp)
+    if case == "new_columns":      # the same handle gets other columns: the merged rows follow (O3 doubled, N2O varies)
+        g.step(2)
+        gas[:, 2] *= 2.0
+        gas[:, 3] *= rng.uniform(0.5, 2.0, (ncol, 1))
+        c = inp["cols"]
+        g.set_columns(c["Tlayer0"], c["T_surface0"], c["gas"], c["rel_hum"])
+        o = H.oracle_ensemble(olib, inp)
+    for c in range(ncol):
+        np.testing.assert_allclose(g.get_tau_production(c), o.get_tau(c), rtol=1e-12, atol=0)
+    g.step(3), o.step(3)
+    fg, fo = g.get_fluxes(), o.get_fluxes()
+    for k in fg:
+        assert H.max_abs(fg[k], fo[k]) <= FLUX_TIGHT, (case, k)
+    assert H.max_abs(g.get_state()["Tlayer"], o.get_state()["Tlayer"]) <= TEMP_TIGHT
+    for c in (0, ncol - 1):
+        np.testing.assert_allclose(g.get_tau_production(c), o.get_tau(c), rtol=1e-12, atol=0)

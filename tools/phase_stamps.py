@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Phase durations inside the fused repwvl kernel from s_memtime stamps of sampled waves (a library built with
--DRCM_DBG_STAMPS: python tools/build_variants.py stamps:-DRCM_DBG_STAMPS).  usage (GPU box): phase_stamps.py [ncol]"""
+-DRCM_DBG_STAMPS: python tools/build_variants.py stamps:-DRCM_DBG_STAMPS,-DRCM_WITH_VARIANTS).
+usage (GPU box): phase_stamps.py [ncol] [fused|flat] [variant name = stamps]"""
 import ctypes as C
 import os
 import sys
@@ -15,7 +16,8 @@ import our_first_climate_model_amd as pkg
 
 ncol = int(sys.argv[1]) if len(sys.argv) > 1 else 10000
 mode = sys.argv[2] if len(sys.argv) > 2 else "fused"
-L = pkg.load_library(os.path.join(ROOT, "our_first_climate_model_amd", "variants", "librcm_hip_stamps.so"))
+vname = sys.argv[3] if len(sys.argv) > 3 else "stamps"
+L = pkg.load_library(os.path.join(ROOT, "our_first_climate_model_amd", "variants", f"librcm_hip_{vname}.so"))
 L.rcm_dbg_stamps.argtypes = [C.c_void_p, C.POINTER(C.c_ulonglong), C.c_int]
 inp = H.make_inputs(pkg, "repwvl", ncol, table="Reduced100")
 g = H.gpu_ensemble(pkg, inp, library=L)
