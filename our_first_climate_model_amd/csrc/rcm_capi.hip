@@ -57,7 +57,7 @@ struct rcm_ensemble {
   // repwvl host copies needed to (re)derive per-layer constants
   std::vector<double> p_grid;
   std::vector<double> xsec_t;  // xsec re-laid out [t][s][p][w] (host copy: the per-layer table is re-derived with the grid)
-  double *d_xp = nullptr;      // [layer][t][s][w]: xsec interpolated to the layer's mid pressure (derive_repwvl_layers)
+  double *d_xp = nullptr;      // [layer][t][s][w][2]: xsec at the layer's mid pressure, pairs of temperature rows (derive_repwvl_layers)
   double *d_tref_l = nullptr;  // [layer]: t_ref[ip[layer]]
   std::vector<double> t_ref;   // host copy
   std::vector<double> shared_vmr;  // [9][NL]: the profiles of the species merged into d.merged_slot (rcm_set_columns)
@@ -153,8 +153,18 @@ int derive_repwvl_layers(rcm_ensemble *h) {
             }
           std::copy(sum.begin(), sum.end(), slot);
         }
-    HIPCK(hipMemcpyAsync(h->d_xp, xp.data(), xp.size() * sizeof(double), hipMemcpyHostToDevice, h->stream));
-    HIPCK(hipStreamSynchronize(h->stream));  // xp goes out of scope
+    // what the kernels read: pairs {x(t), x(t+1)} of neighbouring temperature rows, one 16-byte load per bracket
+    const size_t nt1 = (size_t)d.n_tpert - 1, ns = (size_t)d.n_species;
+    std::vector<double> xq((size_t)NL * nt1 * ns * nw * 2);
+    for (size_t l = 0; l < (size_t)NL; ++l)
+      for (size_t t = 0; t < nt1; ++t)
+        for (size_t sp = 0; sp < ns; ++sp) {
+          const double *lo = &xp[((l * d.n_tpert + t) * ns + sp) * nw], *hi = lo + ns * nw;
+          double *o = &xq[(((l * nt1 + t) * ns + sp) * nw) * 2];
+          for (size_t w = 0; w < nw; ++w) o[2 * w] = lo[w], o[2 * w + 1] = hi[w];
+        }
+    HIPCK(hipMemcpyAsync(h->d_xp, xq.data(), xq.size() * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    HIPCK(hipStreamSynchronize(h->stream));  // xq goes out of scope
   }
   std::vector<double> tref_l(NL);
   for (int l = 0; l < NL; ++l) tref_l[l] = h->t_ref[ip[l]];  // :229: the bracket's reference temperature per layer
@@ -195,6 +205,11 @@ int classify_species(rcm_ensemble *h, const double *gas) {
     d.merged_slot = -1;
     d.prod_mask = d.species_mask;
   }
+  d.nact = 0;
+  for (int s = 0; s < RCM_NSPEC_REPWVL; ++s)
+    if ((d.prod_mask >> s) & 1u) d.act[d.nact++] = s;
+  for (int s = 0, j = d.nact; s < RCM_NSPEC_REPWVL && j < RCM_NSPEC_REPWVL; ++s)  // padding: coefficients 0 in the image
+    if (!((d.prod_mask >> s) & 1u)) d.act[j++] = s;
   bool changed = old_set != h->shared_set;
   for (int s = 0; !changed && s < RCM_NSPEC_REPWVL; ++s)
     if ((h->shared_set >> s) & 1u)
@@ -303,7 +318,11 @@ void launch_rt_pair(rcm_ensemble *h, int blocks) {
     const int maxc = (rcm::FWPB * 32 - 1) / h->d.n_wvl + 2;  // columns the consecutive items of a block can touch
     const size_t lds = (size_t)maxc * sizeof(rcm::RepwvlPairLds) + (size_t)rcm::FWPB * (rcm::NH + 1) * 64 * sizeof(double);
     const long waves = ((long)h->ncol * h->d.n_wvl + 31) / 32;
-    const auto kern = rcm::k_rt_repwvl_flat<CUBE>;
+    // the instantiation that visits the fewest species >= the active ones (the entries past Dev::nact add +0)
+    const int na = h->d.nact;
+    const auto kern = na <= 2 ? rcm::k_rt_repwvl_flat<CUBE, 2> : na <= 3 ? rcm::k_rt_repwvl_flat<CUBE, 3>
+                    : na <= 4 ? rcm::k_rt_repwvl_flat<CUBE, 4> : na <= 5 ? rcm::k_rt_repwvl_flat<CUBE, 5>
+                    : na <= 7 ? rcm::k_rt_repwvl_flat<CUBE, 7> : rcm::k_rt_repwvl_flat<CUBE, 9>;
     if (lds > 48 * 1024)
       (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipLaunchKernelGGL(kern, dim3((unsigned)((waves + rcm::FWPB - 1) / rcm::FWPB)), dim3(64 * rcm::FWPB), lds, h->stream,
@@ -738,7 +757,7 @@ int rcm_set_repwvl_tables(rcm_ensemble *h, int n_tpert, int n_species, int n_wvl
   }
   int rc = 0;
   rc = rc ? rc : dev_upload(h, (double **)&d.xsec, xt.data(), xt.size());
-  rc = rc ? rc : dev_alloc(h, &h->d_xp, (size_t)NL * n_tpert * n_species * n_wvl);
+  rc = rc ? rc : dev_alloc(h, &h->d_xp, (size_t)NL * (n_tpert - 1) * n_species * n_wvl * 2);
   rc = rc ? rc : dev_alloc(h, &h->d_tref_l, (size_t)NL);
   rc = rc ? rc : dev_alloc(h, (char **)&d.img, (size_t)h->ncol * sizeof(rcm::RepwvlPairLds));  // 3.8 KB per column
   d.xp = h->d_xp;
@@ -759,6 +778,8 @@ int rcm_set_repwvl_tables(rcm_ensemble *h, int n_tpert, int n_species, int n_wvl
   d.ngas = RCM_NSPEC_REPWVL;
   d.mode = h->mode = rcm::MODE_REPWVL;
   d.species_mask = d.prod_mask = 0x1ff;
+  d.nact = RCM_NSPEC_REPWVL;
+  for (int s = 0; s < RCM_NSPEC_REPWVL; ++s) d.act[s] = s;
   d.merged_slot = -1;
   h->shared_set = 0;
   return derive_repwvl_layers(h);

@@ -121,7 +121,10 @@ struct Dev {
   long lbl_ld;
   // repwvl: xsec[t][s][p][w] (wavelength fastest)
   const double *xsec, *t_ref, *t_pert, *delP, *numDens, *pnum, *lam5, *lkb;
-  const double *xp;  // [layer][t][s][w]: xsec interpolated to the layer's mid pressure (host, with the grid)
+  // xsec interpolated to each layer's mid pressure (host, with the grid), as PAIRS of neighbouring temperature rows:
+  // xp[layer][t][s][w] = {x(t), x(t+1)}, t = 0 .. n_tpert-2: the two corners of a bracket come in ONE 16-byte load
+  // (the optical-depth stage is bound by the number of load instructions, not by their bytes: profiles/README.md)
+  const double *xp;
   const double *tref_l;  // [layer]: t_ref[ip[layer]], the reference temperature of the layer's pressure bracket (host)
   // repwvl, per column, written at the start of every iteration (k_pre / post_column, repwvl_image_store): the
   // complete column image of the flattened kernel -- temperature brackets, interpolation coefficients with the mixing
@@ -135,7 +138,9 @@ struct Dev {
   // summed into one table row set on the host, xp[l][t][merged_slot][w] = sum_s vmr_s[l] * xp[l][t][s][w]
   // (derive_repwvl_layers): the kernels then load 2 corners for H2O, for every species that does vary, and for the
   // merged one (coefficient: the interpolation weight alone), 60 table loads per point instead of 100.
-  unsigned prod_mask;     // species the production optical-depth stage visits
+  unsigned prod_mask;     // species the production optical-depth stage visits ...
+  int nact;               // ... their number and their list, ascending, padded to 9 entries with species outside the
+  int act[RCM_NSPEC_REPWVL];  // mask (their image coefficients are 0): the stage runs WITHOUT a branch per species
   int merged_slot;        // -1: nothing merged
 };
 
@@ -841,7 +846,7 @@ struct RepwvlPairLds {
   double cA[2][RCM_NSPEC_REPWVL][NH], cB[2][RCM_NSPEC_REPWVL][NH];
   double wA[2][NH], wB[2][NH];  // numDens*(1-delT), numDens*delT (scratch of the image build)
   double cloud[2][NH];   // grey cloud optical depth of the layer (main.cpp:266-274), 0 elsewhere
-  unsigned xoff[2][NH];  // byte offset of xp[l][it][0][0]: the layer's temperature bracket (:229-232)
+  unsigned xoff[2][NH];  // byte offset of xp[l][it][0][0] (pairs): the layer's temperature bracket (:229-232)
 };
 
 // The temperature bracket of read_tau for one layer (repwvl_thermal.cpp:229-239): it = LowerPos(t_ref[ip] +
@@ -878,7 +883,7 @@ __device__ __forceinline__ void repwvl_bracket(const Dev &d, const double (&tp)[
   }
   const double dT = (midT - t0) / (t1 - t0);  // :239
   *wA = nd * (1.0 - dT), *wB = nd * dT;
-  *xoff = (unsigned)((((size_t)layer * d.n_tpert + it) * d.n_species) * d.n_wvl * sizeof(double));
+  *xoff = (unsigned)((((size_t)layer * (d.n_tpert - 1) + it) * d.n_species) * d.n_wvl * 2 * sizeof(double));
 }
 
 // Start of an iteration, repwvl: a whole wave (lane l = layer l for l < NL) writes the image of column c for the
@@ -917,7 +922,8 @@ __device__ __forceinline__ void repwvl_image_store(const Dev &d, int c, int lane
       const int q = i / (RCM_NSPEC_REPWVL * NH), r = i - q * (RCM_NSPEC_REPWVL * NH);
       const int sp = r / NH, k = r - sp * NH;
       const int layer = q ? NL - 1 - k : k;
-      const double vmr = sp == 0 ? scr[2 * NL + layer]
+      const double vmr = !((d.prod_mask >> sp) & 1u) ? 0.0  // not visited, or a padding entry of Dev::act: exactly +0
+                         : sp == 0 ? scr[2 * NL + layer]
                          : sp == d.merged_slot ? 1.0 : d.gas[((size_t)c * RCM_NSPEC_REPWVL + sp) * NL + layer];
       g->cA[q][sp][k] = scr[layer] * vmr;  // :244 and :246 folded into the interpolation weights
       g->cB[q][sp][k] = scr[NL + layer] * vmr;
@@ -945,7 +951,8 @@ __device__ __forceinline__ void repwvl_pair_image_from(const Dev &d, int col, in
     const int sp = r / NH, k = r - sp * NH;
     const int layer = q ? NL - 1 - k : k;
     vmr[m] = (i < 2 * RCM_NSPEC_REPWVL * NH)
-                 ? (sp == 0 ? h2o[layer]
+                 ? (!((d.prod_mask >> sp) & 1u) ? 0.0
+                    : sp == 0 ? h2o[layer]
                     : sp == d.merged_slot ? 1.0 : d.gas[((size_t)col * RCM_NSPEC_REPWVL + sp) * NL + layer])
                  : 0.0;
   }
@@ -987,12 +994,12 @@ __device__ __forceinline__ void repwvl_pair_image_copy(const Dev &d, int col, in
   static_assert(sizeof(RepwvlPairLds) % 16 == 0, "copied in 16-byte pieces");
   const double2 *src = reinterpret_cast<const double2 *>(reinterpret_cast<const RepwvlPairLds *>(d.img) + col);
   double2 *dst = reinterpret_cast<double2 *>(&s);
-  constexpr int n16 = (int)(sizeof(RepwvlPairLds) / 16);
+  constexpr int n16 = (int)(sizeof(RepwvlPairLds) / 16), rounds = (n16 + 63) / 64;
+  double2 v[rounds];  // every load first, then every store, no branch in between (a lane past the end copies the last
+#pragma unroll        // piece once more): ONE wait for memory, not one per round
+  for (int m = 0; m < rounds; ++m) v[m] = src[min(lane + 64 * m, n16 - 1)];
 #pragma unroll
-  for (int m = 0; m < (n16 + 63) / 64; ++m) {
-    const int i = lane + 64 * m;
-    if (i < n16) dst[i] = src[i];
-  }
+  for (int m = 0; m < rounds; ++m) dst[min(lane + 64 * m, n16 - 1)] = v[m];
 }
 
 __device__ __forceinline__ void repwvl_pair_image(const Dev &d, int col, int lane, RepwvlPairLds &s) {
@@ -1003,26 +1010,32 @@ __device__ __forceinline__ void repwvl_pair_image(const Dev &d, int col, int lan
 // Optical depths of the lane's ten layers at wavelength w (read_tau :210-246 + cloud, main.cpp:266-274), clamped
 // once, into the lane's staging column st[0..9][lane].  THE optical-depth arithmetic of the production repwvl
 // kernels; k_tau_pair dumps it.  s = the lane's column image.
+// NACT: how many entries of Dev::act are visited (>= Dev::nact; the entries past nact add exactly +0).  A uniform
+// BRANCH per species (an earlier version skipped the species outside the mask that way) makes every load wait for
+// itself: 30 round trips to L2 in a row, a quarter of the wave's life (profiles/README.md); a fixed count lets the
+// compiler send all loads of the stage first.
+template <int NACT>
 __device__ __forceinline__ void repwvl_pair_tau(const Dev &d, const RepwvlPairLds &s, int p, int w, double (*st)[64],
                                                 int lane) {
-  // xp[l][t][s][w]: the two temperature corners of a layer's bracket are n_species*n_wvl doubles apart, the
-  // species n_wvl: two scalar bases + one 32-bit byte offset per (layer, species) address them (the table is
+  // xp[l][t][s][w] = {x(t), x(t+1)}: both temperature corners of a layer's bracket in one 16-byte load; the species
+  // are n_wvl pairs apart: one scalar base + one 32-bit byte offset per (layer, species) address them (the table is
   // < 4 GiB, rcm_set_repwvl_tables checks)
-  const unsigned ld8 = (unsigned)d.n_wvl * 8u;
-  const char *bA = (const char *)d.xp, *bB = bA + (size_t)d.n_species * ld8;
+  typedef double corner_pair __attribute__((ext_vector_type(2)));
+  const unsigned ld16 = (unsigned)d.n_wvl * 16u;
+  const char *bA = (const char *)d.xp;
 #pragma unroll RCM_RW_TAU_UNROLL
   for (int k = 0; k < NH; ++k) {
 #ifdef RCM_DBG_NOLOAD  // ablation builds only (tools/build_variants.py): every lane reads one address
-    const unsigned vo = (s.xoff[p][k] + (unsigned)w * 8u) & 0u;
+    const unsigned vo = (s.xoff[p][k] + (unsigned)w * 16u) & 0u;
 #else
-    const unsigned vo = s.xoff[p][k] + (unsigned)w * 8u;
+    const unsigned vo = s.xoff[p][k] + (unsigned)w * 16u;
 #endif
     double a = 0.0;
 #pragma unroll
-    for (int sp = 0; sp < RCM_NSPEC_REPWVL; ++sp) {
-      if (!((d.prod_mask >> sp) & 1u)) continue;  // vmr == 0 everywhere (the term is +0), or merged into another row
-      const unsigned v = vo + (unsigned)sp * ld8;
-      a = fma(s.cA[p][sp][k], *(const double *)(bA + v), fma(s.cB[p][sp][k], *(const double *)(bB + v), a));
+    for (int j = 0; j < NACT; ++j) {
+      const int sp = d.act[j];  // (wave-uniform)
+      const corner_pair x = *(const corner_pair *)(bA + vo + (unsigned)sp * ld16);
+      a = fma(s.cA[p][sp][k], x.x, fma(s.cB[p][sp][k], x.y, a));
     }
     st[k][lane] = clamp_tau(a + s.cloud[p][k]);  // main.cpp:266-274; + 0.0 leaves the other layers as they are
   }
@@ -1030,12 +1043,12 @@ __device__ __forceinline__ void repwvl_pair_tau(const Dev &d, const RepwvlPairLd
 
 // One wavelength on a lane pair: optical depths, monochromatic Planck (main.cpp:186-204), all angles.
 // s = the lane's column image, st = the wave's staging column.
-template <int CUBE>
+template <int CUBE, int NACT = RCM_NSPEC_REPWVL>
 __device__ __forceinline__ void repwvl_pair_point(const Dev &d, const RepwvlPairLds &s, int p, int w, int lane,
                                                   double (*st)[64], double (&acc1)[NH + 1], double (&acc2)[NH]) {
   double tau[NH];
   RCM_PT_STAMP(20);
-  repwvl_pair_tau(d, s, p, w, st, lane);
+  repwvl_pair_tau<NACT>(d, s, p, w, st, lane);
 #pragma unroll
   for (int k = 0; k < NH; ++k) tau[k] = st[k][lane];
   RCM_PT_STAMP(21);
@@ -1222,7 +1235,7 @@ constexpr int FWPB = RCM_FLAT_WPB;
 #ifndef RCM_FLAT_LB
 #define RCM_FLAT_LB 4  // waves per SIMD k_rt_repwvl_flat is register-allocated for
 #endif
-template <int CUBE>
+template <int CUBE, int NACT>
 __global__ __launch_bounds__(64 * FWPB, RCM_FLAT_LB) void k_rt_repwvl_flat(Dev d, int maxc) {
   extern __shared__ __align__(16) unsigned char s_dyn[];
   int lane = threadIdx.x & 63;
@@ -1260,7 +1273,7 @@ __global__ __launch_bounds__(64 * FWPB, RCM_FLAT_LB) void k_rt_repwvl_flat(Dev d
   int col = -1;
   if (flat < nflat) {
     col = (int)(flat / nw);
-    repwvl_pair_point<CUBE>(d, imgs[col - cb_first], p, (int)(flat - (long)col * nw), lane, st, acc1, acc2);
+    repwvl_pair_point<CUBE, NACT>(d, imgs[col - cb_first], p, (int)(flat - (long)col * nw), lane, st, acc1, acc2);
   }
   if (flat0 >= nflat) return;  // (whole wave)
 
@@ -1813,7 +1826,7 @@ __global__ __launch_bounds__(64) void k_tau_pair(Dev d, int col, double *out) {
   const long b = (long)blockIdx.x * 32 + (d.mode == MODE_REPWVL ? PairRw::index(lane) : PairLbl::index(lane));
   if (b >= d.nspec) return;
   if (d.mode == MODE_REPWVL) {
-    repwvl_pair_tau(d, img.rw, p, (int)b, st, lane);
+    repwvl_pair_tau<RCM_NSPEC_REPWVL>(d, img.rw, p, (int)b, st, lane);
   } else {
     const LblAddr ad = lbl_pair_addr(d, p);
     lbl_pair_tau(img.lbl, p, ad.sbase, ad.row0 + (unsigned)b * 8u, ad.rstep, st, lane);

@@ -13,7 +13,7 @@ kn = sys.argv[2] if len(sys.argv) > 2 else "k_rt_lbl_pair"
 out = {}
 for which in ("product", v):
     acc = defaultdict(list)
-    for grp in "ab":
+    for grp in "abg":
         for f in glob.glob(os.path.join(ROOT, "gpurun_out", f"pc_{which}_{grp}", "**", "*counter_collection.csv"), recursive=True):
             per = defaultdict(float)
             for row in csv.DictReader(open(f)):
