@@ -210,6 +210,10 @@ int classify_species(rcm_ensemble *h, const double *gas) {
     if ((d.prod_mask >> s) & 1u) d.act[d.nact++] = s;
   for (int s = 0, j = d.nact; s < RCM_NSPEC_REPWVL && j < RCM_NSPEC_REPWVL; ++s)  // padding: coefficients 0 in the image
     if (!((d.prod_mask >> s) & 1u)) d.act[j++] = s;
+  d.act_nibbles = 0;
+  for (int j = 0; j < RCM_NSPEC_REPWVL; ++j) d.act_nibbles |= (unsigned long long)d.act[j] << (4 * j);
+  // k_pre / k_post_wave write the coefficients of the active species only: everything else in the images is zero
+  HIPCK(hipMemsetAsync(d.img, 0, (size_t)h->ncol * sizeof(rcm::RepwvlPairLds), h->stream));
   bool changed = old_set != h->shared_set;
   for (int s = 0; !changed && s < RCM_NSPEC_REPWVL; ++s)
     if ((h->shared_set >> s) & 1u)
@@ -779,7 +783,8 @@ int rcm_set_repwvl_tables(rcm_ensemble *h, int n_tpert, int n_species, int n_wvl
   d.mode = h->mode = rcm::MODE_REPWVL;
   d.species_mask = d.prod_mask = 0x1ff;
   d.nact = RCM_NSPEC_REPWVL;
-  for (int s = 0; s < RCM_NSPEC_REPWVL; ++s) d.act[s] = s;
+  d.act_nibbles = 0;
+  for (int s = 0; s < RCM_NSPEC_REPWVL; ++s) d.act[s] = s, d.act_nibbles |= (unsigned long long)s << (4 * s);
   d.merged_slot = -1;
   h->shared_set = 0;
   return derive_repwvl_layers(h);

@@ -141,6 +141,7 @@ struct Dev {
   unsigned prod_mask;     // species the production optical-depth stage visits ...
   int nact;               // ... their number and their list, ascending, padded to 9 entries with species outside the
   int act[RCM_NSPEC_REPWVL];  // mask (their image coefficients are 0): the stage runs WITHOUT a branch per species
+  unsigned long long act_nibbles;  // the same list, 4 bits per entry (a per-lane lookup without an indexed array)
   int merged_slot;        // -1: nothing merged
 };
 
@@ -914,20 +915,19 @@ __device__ __forceinline__ void repwvl_image_store(const Dev &d, int c, int lane
     g->rT[0][NH] = r, g->rT[1][NH] = r;
   }
   __builtin_amdgcn_wave_barrier();  // one wave: its LDS operations execute in program order
-  constexpr int kPerLane = (2 * RCM_NSPEC_REPWVL * NH + 63) / 64;
-#pragma unroll
-  for (int m = 0; m < kPerLane; ++m) {
-    const int i = lane + 64 * m;
-    if (i < 2 * RCM_NSPEC_REPWVL * NH) {
-      const int q = i / (RCM_NSPEC_REPWVL * NH), r = i - q * (RCM_NSPEC_REPWVL * NH);
-      const int sp = r / NH, k = r - sp * NH;
-      const int layer = q ? NL - 1 - k : k;
-      const double vmr = !((d.prod_mask >> sp) & 1u) ? 0.0  // not visited, or a padding entry of Dev::act: exactly +0
-                         : sp == 0 ? scr[2 * NL + layer]
-                         : sp == d.merged_slot ? 1.0 : d.gas[((size_t)c * RCM_NSPEC_REPWVL + sp) * NL + layer];
-      g->cA[q][sp][k] = scr[layer] * vmr;  // :244 and :246 folded into the interpolation weights
-      g->cB[q][sp][k] = scr[NL + layer] * vmr;
-    }
+  // the coefficients of the ACTIVE species only (2 parities x nact x 10 layers: one round of the wave for three
+  // species): the others are zero since the buffer was cleared (rcm_set_columns, whenever the species pattern changes)
+  const int per_parity = d.nact * NH, items = 2 * per_parity;
+  for (int i = lane; i < items; i += 64) {
+    const int q = i >= per_parity, r = i - q * per_parity;
+    const int a = r / NH, k = r - a * NH;
+    const int sp = (int)((d.act_nibbles >> (4 * a)) & 15u);
+    const int layer = q ? NL - 1 - k : k;
+    double vmr = scr[2 * NL + layer];  // H2O: this iteration's mixing ratio
+    if (sp == d.merged_slot) vmr = 1.0;
+    else if (sp != 0) vmr = d.gas[((size_t)c * RCM_NSPEC_REPWVL + sp) * NL + layer];
+    g->cA[q][sp][k] = scr[layer] * vmr;  // :244 and :246 folded into the interpolation weights
+    g->cB[q][sp][k] = scr[NL + layer] * vmr;
   }
 }
 
