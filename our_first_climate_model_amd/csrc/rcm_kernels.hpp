@@ -136,8 +136,8 @@ struct Dev {
   unsigned species_mask;  // species with a non-zero mixing ratio somewhere (the reference-form getter and kernels)
   // Production kernels: species whose mixing-ratio profile is THE SAME IN EVERY COLUMN (O3, N2O, CH4 in a CO2 sweep) are
   // summed into one table row set on the host, xp[l][t][merged_slot][w] = sum_s vmr_s[l] * xp[l][t][s][w]
-  // (derive_repwvl_layers): the kernels then load 2 corners for H2O, for every species that does vary, and for the
-  // merged one (coefficient: the interpolation weight alone), 60 table loads per point instead of 100.
+  // (derive_repwvl_layers): the kernels then load the bracket's corner pair for H2O, for every species that does vary,
+  // and for the merged one (coefficient: the interpolation weight alone): 3 x 20 pairs per point instead of 5 x 20.
   unsigned prod_mask;     // species the production optical-depth stage visits ...
   int nact;               // ... their number and their list, ascending, padded to 9 entries with species outside the
   int act[RCM_NSPEC_REPWVL];  // mask (their image coefficients are 0): the stage runs WITHOUT a branch per species
