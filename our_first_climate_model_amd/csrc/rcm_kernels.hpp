@@ -843,7 +843,7 @@ struct RepwvlPairLds {
   // table xp (derive_repwvl_layers): cA = numDens*(1-delT)*vmr, cB = numDens*delT*vmr, so that
   //   tau = sum_s cA_s * xp[l][it][s][w] + cB_s * xp[l][it+1][s][w]
   // is read_tau's numDens * sum_s vmr_s * (c0 + cT*delT + cP*delP + cPT*delT*delP) (:235-246) up to rounding
-  // (rcm_get_tau, k_tau, keeps the reference's corner-difference form): 2 loads and 2 FMAs per species and layer.
+  // (rcm_get_tau, k_tau, keeps the reference's corner-difference form): one 16-byte load and 2 FMAs per species and layer.
   double cA[2][RCM_NSPEC_REPWVL][NH], cB[2][RCM_NSPEC_REPWVL][NH];
   double wA[2][NH], wB[2][NH];  // numDens*(1-delT), numDens*delT (scratch of the image build)
   double cloud[2][NH];   // grey cloud optical depth of the layer (main.cpp:266-274), 0 elsewhere
