@@ -9,15 +9,17 @@
  * links nor loads it.
  *
  * Parity pinning (see oracle/README.md, DESIGN.md section "Oracle"):
- *   - solar known answers and the t=0 rows from the reference's output.txt,
- *   - PARITY UNPINNED for Planck / sweep / read_tau / time step: the [probe]
- *     outputs recorded in SURVEY.md section 8(c) (tests/golden/survey_probe.json), which this file
- *     reproduces bit for bit, come from a build with a stand-in <netcdf> header and pin nothing,
- *   - cplkavg.cpp known answers + the reference cplkavg.cpp compiled as-is
- *     into oracle/_ref/ (it needs only libm),
- *   - the reference ascii.cpp compiled as-is into oracle/_ref/.
- * main.cpp / repwvl_thermal.cpp need <netcdf> (netcdf-cxx4), absent from this
- * image: unbuildable here, so that part is pinned by the recorded outputs.
+ *   - PINNED, bit for bit, by the reference's own code compiled here from where it lies (oracle/Makefile ->
+ *     oracle/_ref/libref_main.so = main.cpp:12-21,25-344 unedited + C-linkage call-throughs): Planck,
+ *     emissivity, monochromatic_radiative_transfer, radiative_transfer, cloud_into_tau, calculate_timestep,
+ *     thermodynamics, adjustment, magnus, water_vapor_feedback, solar set-up (SURVEY.md 8 rows a1-a4, a5',
+ *     a6-a8), incl. 101 chained iterations; LowerPos (libref_lowerpos.so); cplkavg.cpp and ascii.cpp as whole
+ *     translation units (a10, f1); tests/test_reference_pins.py, tests/test_oracle_pins.py,
+ *   - PINNED by reference-held data: solar banners and the t=0 rows of the reference's output.txt,
+ *   - PARITY UNPINNED for the interpolation arithmetic of read_tau (a5, repwvl_thermal.cpp:197-248: it reads
+ *     through netCDF::NcVar inside the loop; netcdf-cxx4 is absent and no stand-in header is allowed) --
+ *     corroborated only by the outputs SURVEY.md 8(c) recorded (tests/golden/survey_probe.json) -- and for
+ *     the lbl composition (a9: no reference driver exists).
  *
  * Conventions: layer index 0 = top of atmosphere; all arrays row-major;
  * everything double except `time` (float, main.cpp:359).

@@ -47,6 +47,14 @@ def load():
     lib.orc_radiative_transfer.argtypes = [C.c_int] * 3 + [_dp] * 3 + [C.c_int, _dp, C.c_double,
                                                                       C.c_double] + [_dp] * 3
     lib.orc_radiative_transfer.restype = None
+    lib.orc_cloud_into_tau.argtypes = [_dp, C.c_int, C.c_int, C.c_int, C.c_double]
+    lib.orc_cloud_into_tau.restype = None
+    lib.orc_thermodynamics.argtypes = [_dp, C.c_int, C.c_double, _dp, C.c_double, _dp, _dp]
+    lib.orc_thermodynamics.restype = None
+    lib.orc_convective_adjustment.argtypes = [_dp, _dp, _dp, C.c_int]
+    lib.orc_convective_adjustment.restype = None
+    lib.orc_water_vapor_feedback.argtypes = [_dp, _dp, _dp, _dp, C.c_int]
+    lib.orc_water_vapor_feedback.restype = None
     lib.orc_rtab_load.argtypes = [C.c_char_p, C.POINTER(C.c_longlong), C.POINTER(_dp)]
     lib.orc_free.argtypes = [C.c_void_p]
     lib.orc_free.restype = None
@@ -241,3 +249,71 @@ class OracleEnsemble:
 
     def threads_used(self):
         return self.lib.orc_threads_used(self.h)
+
+
+# ---- the reference's own code, compiled from where it lies into oracle/_ref/ (oracle/Makefile) -------------
+
+REF_DIR = os.path.join(ROOT, "oracle", "_ref")
+
+
+def load_ref_main():
+    """oracle/_ref/libref_main.so = /root/reference/main.cpp:12-21,25-344 (unedited) + oracle/ref_main_shim.inc.
+    Returns None when it was not built (no reference tree at build time and no prebuilt copy)."""
+    p = os.path.join(REF_DIR, "libref_main.so")
+    if not os.path.exists(p):
+        return None
+    L = C.CDLL(p)
+    d, i = C.c_double, C.c_int
+    L.ref_consts.argtypes = [_dp]
+    L.ref_cplkavg_layers.argtypes = [d, d, _dp, _dp]
+    L.ref_cplkavg_scalar.restype = d
+    L.ref_cplkavg_scalar.argtypes = [d, d, d]
+    L.ref_emissivity.argtypes = [_dp, d, _dp]
+    L.ref_monochromatic_radiative_transfer.argtypes = [_dp, i, _dp, d, i, _dp, _dp, d, _dp, d, _dp, _dp]
+    L.ref_radiative_transfer.argtypes = [i, _dp, _dp, _dp, _dp, d, _dp, d, d, _dp, _dp, _dp]
+    L.ref_calculate_timestep.restype = d
+    L.ref_calculate_timestep.argtypes = [d, _dp]
+    L.ref_thermodynamics.restype = d
+    L.ref_thermodynamics.argtypes = [_dp, d, _dp, d, _dp]
+    L.ref_convective_adjustment.argtypes = [_dp, _dp, _dp]
+    L.ref_VMR_level_to_layer.argtypes = [_dp, _dp]
+    L.ref_magnus.restype = d
+    L.ref_magnus.argtypes = [d]
+    L.ref_water_vapor_feedback.argtypes = [_dp, _dp, _dp, _dp]
+    L.ref_cloud_into_tau.argtypes = [_dp, i]
+    L.ref_solar.argtypes = [_dp]
+    for n in ("ref_consts", "ref_cplkavg_layers", "ref_emissivity", "ref_monochromatic_radiative_transfer",
+              "ref_radiative_transfer", "ref_convective_adjustment", "ref_VMR_level_to_layer",
+              "ref_water_vapor_feedback", "ref_cloud_into_tau", "ref_solar"):
+        getattr(L, n).restype = None
+    return L
+
+
+def load_ref_lowerpos():
+    p = os.path.join(REF_DIR, "libref_lowerpos.so")
+    if not os.path.exists(p):
+        return None
+    L = C.CDLL(p)
+    L.ref_lower_pos.argtypes = [_dp, C.c_int, C.c_double]
+    L.ref_lower_pos.restype = C.c_int
+    return L
+
+
+def ref_mu(nangle=30):
+    """main.cpp:355,481-482: dmu = 1/nangle, mu[i] = dmu/2 + dmu*i (the same IEEE operations)."""
+    dmu = 1.0 / float(nangle)
+    return np.array([dmu / 2.0 + dmu * float(i) for i in range(nangle)]), dmu
+
+
+def ref_radiative_transfer(L, tau, wvl, weight, Tlayer, T_surface, solar_irr):
+    """The reference's radiative_transfer (main.cpp:320-344) on [nwvl][20] optical depths."""
+    tau = np.ascontiguousarray(tau, dtype=np.float64)
+    wvl = np.ascontiguousarray(wvl, dtype=np.float64)
+    weight = np.ascontiguousarray(weight, dtype=np.float64)
+    T = np.ascontiguousarray(Tlayer, dtype=np.float64)
+    assert tau.shape == (wvl.size, 20) and weight.shape == wvl.shape and T.shape == (20,)
+    mu, dmu = ref_mu()
+    Ed, Eu, dE = np.zeros(21), np.zeros(21), np.zeros(20)
+    L.ref_radiative_transfer(wvl.size, _p(tau), _p(wvl), _p(weight), _p(mu), dmu, _p(T), float(T_surface),
+                             float(solar_irr), _p(Ed), _p(Eu), _p(dE))
+    return Ed, Eu, dE

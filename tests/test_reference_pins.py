@@ -1,0 +1,300 @@
+"""CPU: the oracle against the reference's OWN CODE, compiled here.
+
+oracle/_ref/libref_main.so is /root/reference/main.cpp's netCDF-free body (:12-21 standard includes, :25-344
+Consts + every free function above main()), piped unedited from where it lies into g++ together with
+oracle/ref_main_shim.inc (C-linkage call-throughs).  No stand-in header, no edited line; main.cpp:22 (<netcdf>) is
+used by main() alone.  These tests assert  oracle/rcm_oracle.c == that compiled code BIT FOR BIT  on
+
+  a1  cplkavg (monochromatic Planck x weight)      main.cpp:186-204
+  a2  emissivity                                   main.cpp:207-212
+  a3  monochromatic_radiative_transfer             main.cpp:291-318
+  a4  radiative_transfer                           main.cpp:320-344
+  a5' cloud_into_tau                               main.cpp:266-274
+  a6  calculate_timestep                           main.cpp:156-162
+  a7  thermodynamics                               main.cpp:164-176
+  a8  t_to_theta / sort / theta_to_t, magnus, water_vapor_feedback   main.cpp:123-139, 277-289, 536-540
+  solar set-up                                     main.cpp:214-264
+  a5  LowerPos only (repwvl_thermal.cpp:19-45, libref_lowerpos.so); the interpolation statements of read_tau
+      read through netCDF::NcVar inside the loop and are NOT compiled: a5's arithmetic stays unpinned.
+
+On the GPU box /root/reference does not exist; the prebuilt oracle/_ref/*.so travel with gpurun.  Without them
+(a fresh clone with no reference tree) the tests skip and say so.
+"""
+import math
+import os
+
+import numpy as np
+import pytest
+
+import oracle_lib as ol
+
+_p = ol._p
+
+
+@pytest.fixture(scope="module")
+def ref():
+    L = ol.load_ref_main()
+    if L is None:
+        pytest.skip("oracle/_ref/libref_main.so not built (reference tree absent at build time)")
+    return L
+
+
+def _column(olib, golden, co2=1.0):
+    atm, _ = ol.atm_load(olib, os.path.join(golden, "test.atm"))
+    return atm, ol.column_init(olib, atm, co2, 1.0)
+
+
+def _orc_tau(olib, t, ci, Tlayer, vmr9, cloud=True):
+    tau = np.zeros((t["n_wvl"], 20))
+    xs = np.ascontiguousarray(t["xsec"])
+    olib.orc_read_tau(t["n_tpert"], t["n_species"], t["n_wvl"], t["n_p"], _p(t["p_grid"]), _p(t["t_ref"]),
+                      _p(t["t_pert"]), _p(xs), 21, _p(ci["plevel"]), _p(np.ascontiguousarray(Tlayer)),
+                      _p(np.ascontiguousarray(vmr9)), _p(tau))
+    if cloud:
+        olib.orc_cloud_into_tau(_p(tau), t["n_wvl"], 20, 17, 1.0)
+    return tau
+
+
+def _orc_rt(olib, tau, wvl, weight, T, Ts, solar):
+    Ed, Eu, dE = np.zeros(21), np.zeros(21), np.zeros(20)
+    tau = np.ascontiguousarray(tau)
+    olib.orc_radiative_transfer(tau.shape[0], 20, 30, _p(tau), _p(np.ascontiguousarray(wvl)),
+                                _p(np.ascontiguousarray(weight)), 0, _p(np.ascontiguousarray(T)), float(Ts),
+                                float(solar), _p(Ed), _p(Eu), _p(dE))
+    return Ed, Eu, dE
+
+
+def test_compiled_in_constants_are_the_ones_the_build_uses(ref, olib, rcm):
+    """Consts (main.cpp:66-91) as compiled, against the defaults of the oracle and of the product's host side."""
+    c = np.zeros(20)
+    ref.ref_consts(_p(c))
+    assert c[0] == 2.0 / 7.0 and c[1] == 1004 and c[2] == 9.80665 and c[3] == 1361.0
+    assert (c[4], c[5], c[6], c[7]) == (6.62607e-34, 299792458.0, 1.380649e-23, 273.15)
+    assert tuple(c[8:12]) == (20, 21, 30, 5.0)
+    assert c[12] == 2.0 and c[13] == np.cos(60 * np.pi / 180.0) and c[14] == 20 and c[15] == 0.85
+    assert c[16] == 0.12 and c[17] == 0.5 and c[18] == 17 and c[19] == 10
+    sol_ref, sol_orc = np.zeros(7), np.zeros(7)
+    ref.ref_solar(_p(sol_ref))
+    olib.orc_default_solar(_p(sol_orc))
+    assert sol_ref.tolist() == sol_orc.tolist()                      # doubling_adding + setup, bit for bit
+    assert list(rcm.default_solar().values()) == sol_ref.tolist()    # ... and the product's host function
+    sol2 = np.zeros(7)
+    olib.orc_solar_setup(c[12], c[13], int(c[14]), c[15], c[16], c[17], c[3], _p(sol2))
+    assert sol2.tolist() == sol_ref.tolist()
+
+
+def test_planck_bit_identical(ref, olib):
+    """a1: both cplkavg overloads of main.cpp:186-204 over the repwvl wavelength range and beyond, weights of both
+    signs (Reduced100's ChosenWeights reach -46 250), temperatures 100-400 K and the underflow/overflow ends."""
+    rng = np.random.default_rng(11)
+    for _ in range(3000):
+        wvl = float(np.exp(rng.uniform(np.log(300.0), np.log(5e5))))
+        w = float(rng.choice([1.0, rng.normal() * 10 ** rng.uniform(-3, 6)]))
+        T = float(rng.uniform(100.0, 400.0)) if rng.random() < 0.9 else float(10 ** rng.uniform(-1, 4))
+        assert olib.orc_planck_mono(wvl, w, T) == ref.ref_cplkavg_scalar(wvl, w, T), (wvl, w, T)
+    for _ in range(200):
+        wvl = float(np.exp(rng.uniform(np.log(3000.0), np.log(2e5))))
+        w = float(rng.normal() * 1e4)
+        T = rng.uniform(150.0, 330.0, 20)
+        B = np.zeros(20)
+        ref.ref_cplkavg_layers(wvl, w, _p(T), _p(B))
+        assert B.tolist() == [olib.orc_planck_mono(wvl, w, float(t)) for t in T]
+
+
+def test_emissivity_and_single_wavelength_sweep_bit_identical(ref, olib):
+    """a2 + a3: one wavelength through the reference's monochromatic_radiative_transfer against the oracle's
+    radiative_transfer with nspec = 1 (whose E_down/E_up start from zero like the reference's fill)."""
+    rng = np.random.default_rng(5)
+    mu, dmu = ol.ref_mu()
+    for case in range(300):
+        tau = 10 ** rng.uniform(-8, 4.5, 20)
+        if case % 7 == 0:
+            tau[rng.integers(0, 20)] = 0.0
+        wvl = np.array([float(np.exp(rng.uniform(np.log(3000.0), np.log(2e5))))])
+        wt = float(rng.normal() * 10 ** rng.uniform(0, 5))
+        T = rng.uniform(180.0, 320.0, 20)
+        Ts = float(rng.uniform(250.0, 330.0))
+        # emissivity alone: 1 - exp(-tau/mu) as the reference's libm call forms it
+        t30, a30 = np.concatenate([tau, np.zeros(10)]), np.zeros(30)
+        ref.ref_emissivity(_p(t30), float(mu[case % 30]), _p(a30))
+        assert a30[:20].tolist() == [1.0 - math.exp(-x / mu[case % 30]) for x in tau]   # the same glibc exp
+        assert a30[20:].tolist() == [0.0] * 10
+        B = np.zeros(20)
+        ref.ref_cplkavg_layers(float(wvl[0]), wt, _p(T), _p(B))
+        Ed, Eu = np.zeros(21), np.zeros(21)
+        ref.ref_monochromatic_radiative_transfer(_p(B), 0, _p(tau), wt, 1, _p(wvl), _p(mu), dmu, _p(T), Ts,
+                                                 _p(Ed), _p(Eu))
+        Ed_o, Eu_o, _ = _orc_rt(olib, tau[None], wvl, np.array([wt]), T, Ts, 0.0)
+        assert Ed.tolist() == Ed_o.tolist() and Eu.tolist() == Eu_o.tolist(), case
+
+
+def test_radiative_transfer_bit_identical_on_random_cases(ref, olib):
+    """a4 (ii): 200 random (tau[nwvl][20], T, weight) cases: tau in [1e-8, 3e4], negative weights, 1-120
+    wavelengths, any solar term."""
+    rng = np.random.default_rng(20260104)
+    for case in range(200):
+        nw = int(rng.integers(1, 121))
+        tau = 10 ** rng.uniform(-8, np.log10(3e4), (nw, 20))
+        wvl = np.sort(np.exp(rng.uniform(np.log(3000.0), np.log(2e5), nw)))
+        wt = rng.normal(size=nw) * 10 ** rng.uniform(0, 5.6, nw)
+        wt[rng.integers(0, nw)] = -46250.7
+        T = rng.uniform(180.0, 320.0, 20)
+        Ts, solar = float(rng.uniform(250.0, 330.0)), float(rng.uniform(0.0, 400.0))
+        got = _orc_rt(olib, tau, wvl, wt, T, Ts, solar)
+        want = ol.ref_radiative_transfer(ref, tau, wvl, wt, T, Ts, solar)
+        for g, w, name in zip(got, want, ("E_down", "E_up", "dE")):
+            assert g.tolist() == w.tolist(), (case, name)
+
+
+@pytest.mark.parametrize("table", ["Reduced10", "Reduced20", "Reduced100"])
+@pytest.mark.parametrize("co2", [1.0, 2.0])
+def test_radiative_transfer_bit_identical_on_the_reference_inputs(ref, olib, golden, table, co2):
+    """a4 (i): test.atm, the reference's tables, step-0 state (tau from the oracle's read_tau: a5 is the one row
+    the compiled reference cannot supply)."""
+    _, ci = _column(olib, golden, co2)
+    t = ol.read_rtab(os.path.join(golden, f"{table}Forcing.rtab"))
+    tau = _orc_tau(olib, t, ci, ci["Tlayer"], ci["vmr9"])
+    sol = np.zeros(7)
+    ref.ref_solar(_p(sol))
+    T, theta = ci["Tlayer"].copy(), np.zeros(20)      # tau from the pre-adjustment profile (main.cpp:500), then
+    ref.ref_convective_adjustment(_p(T), _p(theta), _p(ci["conv"]))   # :536-540: T*f/f moves last bits even when
+    got = _orc_rt(olib, tau, t["wvl"], t["weight"], T, 288.2, sol[6])  # the order of the layers does not change
+    want = ol.ref_radiative_transfer(ref, tau, t["wvl"], t["weight"], T, 288.2, sol[6])
+    for g, w in zip(got, want):
+        assert g.tolist() == w.tolist()
+    # and through the oracle's ensemble handle, the thing every GPU parity test compares with
+    e = ol.OracleEnsemble(olib, 1)
+    e.set_grid(ci["plevel"])
+    e.set_forcing(sol[6])
+    e.set_repwvl_tables(t)
+    e.set_columns(ci["Tlayer"][None], np.array([288.2]), ci["vmr9"][None], ci["rel_hum"][None])
+    e.step(1)
+    f = e.get_fluxes()
+    assert f["E_down"][0].tolist() == want[0].tolist() and f["E_up"][0].tolist() == want[1].tolist()
+    assert f["dE"][0].tolist() == want[2].tolist()
+    assert e.get_state()["timestep"][0] == ref.ref_calculate_timestep(50.0, _p(want[2]))
+
+
+def test_cloud_into_tau_bit_identical(ref, olib):
+    rng = np.random.default_rng(2)
+    tau = 10 ** rng.uniform(-8, 4, (37, 20))
+    a, b = tau.copy(), tau.copy()
+    ref.ref_cloud_into_tau(_p(a), 37)
+    olib.orc_cloud_into_tau(_p(b), 37, 20, 17, 2.0 / 2.0)
+    assert a.tolist() == b.tolist() and (a[:, 17] == tau[:, 17] + 1.0).all() and (np.delete(a, 17, 1) == np.delete(tau, 17, 1)).all()
+
+
+def test_time_step_and_thermodynamics_bit_identical(ref, olib):
+    """a6 + a7: signed maximum (negative and tiny maxima included), the 12 h cap, T update and T_surface."""
+    rng = np.random.default_rng(9)
+    conv = (1000.0 / (np.arange(20) * 50.0 + 25.0)) ** (2.0 / 7.0)
+    for case in range(2000):
+        dE = rng.normal(size=20) * 10 ** rng.uniform(-3, 3)
+        if case % 5 == 0:
+            dE = -np.abs(dE)            # all negative: signed max gives a negative time step (main.cpp:157)
+        if case % 11 == 0:
+            dE *= 1e-4                  # tiny maximum: the 43 200 s cap binds
+        dt_r = ref.ref_calculate_timestep(50.0, _p(dE))
+        dt_o = olib.orc_calculate_timestep(50.0, _p(dE), 20)
+        assert dt_r == dt_o, case
+        T = rng.uniform(180.0, 320.0, 20)
+        Tr, To = T.copy(), T.copy()
+        Ts_o = np.zeros(1)
+        Ts_r = ref.ref_thermodynamics(_p(Tr), 50.0, _p(dE), dt_r, _p(conv))
+        olib.orc_thermodynamics(_p(To), 20, 50.0, _p(dE), dt_o, _p(Ts_o), _p(conv))
+        assert Tr.tolist() == To.tolist() and Ts_r == Ts_o[0], case
+
+
+def test_convective_adjustment_and_feedback_bit_identical(ref, olib, golden):
+    """a8: theta = T * conv, std::sort(greater), back (main.cpp:536-540); magnus + H2O from relative humidity."""
+    rng = np.random.default_rng(13)
+    _, ci = _column(olib, golden)
+    for case in range(1000):
+        T = ci["Tlayer"] + rng.normal(size=20) * (0.0 if case == 0 else 10 ** rng.uniform(-6, 1.5))
+        if case % 9 == 0:
+            T[5] = T[6] * ci["conv"][6] / ci["conv"][5]     # (nearly) equal potential temperatures
+        Tr, To, thr, tho = T.copy(), T.copy(), np.zeros(20), np.zeros(20)
+        ref.ref_convective_adjustment(_p(Tr), _p(thr), _p(ci["conv"]))
+        olib.orc_convective_adjustment(_p(To), _p(tho), _p(ci["conv"]), 20)
+        assert Tr.tolist() == To.tolist() and thr.tolist() == tho.tolist(), case
+        vr, vo = np.zeros(20), np.zeros(20)
+        ref.ref_water_vapor_feedback(_p(Tr), _p(ci["rel_hum"]), _p(ci["player"]), _p(vr))
+        olib.orc_water_vapor_feedback(_p(To), _p(ci["rel_hum"]), _p(ci["player"]), _p(vo), 20)
+        assert vr.tolist() == vo.tolist(), case
+    for T in np.concatenate([np.linspace(150.0, 350.0, 401), [29.0, 30.11, 30.12, 1e3]]):
+        assert ref.ref_magnus(float(T)) == olib.orc_magnus(float(T))
+    lev = rng.uniform(0, 400, 21)
+    a, b = np.zeros(20), np.zeros(20)
+    ref.ref_VMR_level_to_layer(_p(lev), _p(a))
+    assert a.tolist() == ((lev[:-1] + lev[1:]) / 2.0).tolist()
+
+
+@pytest.mark.parametrize("table,co2", [("Reduced10", 1.0), ("Reduced100", 1.0), ("Reduced20", 2.0)])
+def test_101_chained_steps_bit_identical(ref, olib, golden, table, co2):
+    """(iii): the loop body of main.cpp:531-583 driven HERE with the reference's compiled functions -- adjustment,
+    feedback, cloud, radiative_transfer, time step, thermodynamics -- and tau from orc_read_tau (a5, the row the
+    compiled reference cannot supply), against the oracle's own orc_step: state, fluxes and time step identical
+    after every one of the 101 iterations i = 0..100."""
+    _, ci = _column(olib, golden, co2)
+    t = ol.read_rtab(os.path.join(golden, f"{table}Forcing.rtab"))
+    sol = np.zeros(7)
+    ref.ref_solar(_p(sol))
+    e = ol.OracleEnsemble(olib, 1)
+    e.set_grid(ci["plevel"])
+    e.set_forcing(sol[6])
+    e.set_repwvl_tables(t)
+    e.set_columns(ci["Tlayer"][None], np.array([288.2]), ci["vmr9"][None], ci["rel_hum"][None])
+
+    T, Ts, vmr = ci["Tlayer"].copy(), 288.2, ci["vmr9"].copy()
+    time_h = np.float32(0.0)
+    tau = _orc_tau(olib, t, ci, T, vmr, cloud=False)      # main.cpp:500: from the PRE-adjustment profile
+    ref.ref_cloud_into_tau(_p(tau), t["n_wvl"])           # :504
+    theta = np.zeros(20)
+    for i in range(101):
+        ref.ref_convective_adjustment(_p(T), _p(theta), _p(ci["conv"]))             # :536-540
+        if i != 0:                                                                    # :549-572
+            h2o = np.zeros(20)
+            ref.ref_water_vapor_feedback(_p(T), _p(ci["rel_hum"]), _p(ci["player"]), _p(h2o))
+            vmr[0] = h2o
+            tau = _orc_tau(olib, t, ci, T, vmr, cloud=False)
+            ref.ref_cloud_into_tau(_p(tau), t["n_wvl"])
+        Ed, Eu, dE = ol.ref_radiative_transfer(ref, tau, t["wvl"], t["weight"], T, Ts, sol[6])   # :574
+        dt = ref.ref_calculate_timestep(50.0, _p(dE))                                 # :576
+        Ts = ref.ref_thermodynamics(_p(T), 50.0, _p(dE), dt, _p(ci["conv"]))          # :578
+        time_h = np.float32(time_h + np.float32(dt) / np.float32(3600))               # :581, float arithmetic
+        e.step(1)
+        s, f = e.get_state(), e.get_fluxes()
+        assert s["Tlayer"][0].tolist() == T.tolist(), i
+        assert s["T_surface"][0] == Ts and s["timestep"][0] == dt, i
+        assert f["E_down"][0].tolist() == Ed.tolist() and f["E_up"][0].tolist() == Eu.tolist(), i
+        assert f["dE"][0].tolist() == dE.tolist(), i
+        assert s["time_h"][0] == time_h, i
+    assert 295.0 < Ts < 305.0
+
+
+def test_lower_pos_bit_identical(olib, golden):
+    """a5, the bracket search only: LowerPos (repwvl_thermal.cpp:19-45) compiled from the reference against
+    orc_lower_pos on the tables' descending pressure grid, ascending temperature rows, values outside either
+    end, exact grid hits (sgn == 0) and random grids with repeated values."""
+    L = ol.load_ref_lowerpos()
+    if L is None:
+        pytest.skip("oracle/_ref/libref_lowerpos.so not built")
+    t = ol.read_rtab(os.path.join(golden, "Reduced10Forcing.rtab"))
+    rng = np.random.default_rng(4)
+    grids = [t["p_grid"], t["p_grid"][::-1].copy()]
+    grids += [t["t_ref"][k] + t["t_pert"] for k in range(0, 41, 5)]
+    for _ in range(60):
+        g = np.sort(rng.normal(size=int(rng.integers(2, 12)))) * (1 if rng.random() < 0.5 else -1)
+        if rng.random() < 0.3:
+            g[1] = g[0]
+        grids.append(np.ascontiguousarray(g))
+    n = 0
+    for g in grids:
+        g = np.ascontiguousarray(g, dtype=np.float64)
+        lo, hi = g.min(), g.max()
+        xs = list(g) + list((g[:-1] + g[1:]) / 2) + [lo - 1.0, hi + 1.0, lo * 0.999, hi * 1.001]
+        xs += list(rng.uniform(lo - 0.1 * (hi - lo) - 1e-9, hi + 0.1 * (hi - lo) + 1e-9, 50))
+        for x in xs:
+            assert L.ref_lower_pos(_p(g), g.size, float(x)) == olib.orc_lower_pos(_p(g), g.size, float(x)), (g, x)
+            n += 1
+    assert n > 4000
