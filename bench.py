@@ -4,6 +4,11 @@
     python bench.py --gpus N --steps K --warmup W [--workload lbl|repwvl100]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
+Both forms work for any N: started WITHOUT a launcher and with --gpus N > 1, this process -- before it imports
+torch or touches HIP -- starts `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr
+127.0.0.1 --master-port <free> bench.py <same arguments>` as a CHILD process (never exec), passes the child's one
+JSON line through and exits with its return code.
+
 Workloads (BASELINE.json `configs`):
   lbl        (default, the headline) configs[3]: 10 000-column ensemble x the full lbl.arts 5-species spectrum
              (synthetic, 131 072 nodes, seeded: the real lbl.*.asc files are absent from the reference tree)
@@ -75,9 +80,12 @@ def _subset(inp, n):
 
 
 def cpu_baseline(pkg, inp_full, workload, log):
-    """The CPU oracle (a port of the reference; main.cpp itself needs netcdf and cannot be built here) timed on
-    this host's cores on a bounded sample of the same workload: all cores and one core (the reference is
-    single-threaded), full step and radiative transfer alone."""
+    """The CPU oracle (a port of the reference, bit-identical to the reference's compiled functions wherever those
+    exist: tests/test_reference_pins.py; the full step needs read_tau, which needs netcdf and cannot be built
+    here, and the lbl composition has no reference driver -- hence kind "port") timed on this host's cores on a
+    bounded sample of the same workload: all cores and one core (the reference is single-threaded), full step and
+    radiative transfer alone.  For repwvl the reference's OWN compiled radiative_transfer
+    (oracle/_ref/libref_main.so) is timed beside the port when the prebuilt library is there."""
     import ctypes as C
     import numpy as np
     sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -144,6 +152,12 @@ def cpu_baseline(pkg, inp_full, workload, log):
             olib.orc_free(blob)
         dt_load = (time.perf_counter() - t0) / 20
         out["single_core_reread_table_per_step_value"] = 1.0 / (dt1 + dt_load)
+        ref = ol.load_ref_main()
+        if ref is not None:  # the reference's own radiative_transfer (main.cpp:320-344 compiled by oracle/Makefile)
+            t0 = time.perf_counter()
+            for _ in range(reps):
+                ol.ref_radiative_transfer(ref, tau, wvl, wgt, Tl, float(st["T_surface"][0]), float(inp_full["solar"]))
+            out["single_core_rt_only_reference_value"] = reps / (time.perf_counter() - t0)
     return out
 
 
@@ -161,6 +175,24 @@ def valu_issue(tag, kernel_substr, points_per_launch, rt_avg_s):
                 "issue_frac_at_2.4GHz": ipp * points_per_launch * 4 / (N_SIMD * NOMINAL_CLOCK_HZ * rt_avg_s)}, pmc
     except (OSError, KeyError, ValueError):
         return None, None
+
+
+def self_launch(ngpus):
+    """`python bench.py --gpus N` with N > 1 and no launcher: one rank per GPU under torch.distributed.run, as a
+    child process.  Runs before torch is imported, so this process never initialises the GPU."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC: RCCL between processes needs it on this driver
+    env.setdefault("OMP_NUM_THREADS", "1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={ngpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    print(f"[bench] --gpus {ngpus} without a launcher: starting {' '.join(cmd[1:8])} ...", file=sys.stderr, flush=True)
+    sys.stdout.flush()
+    return subprocess.run(cmd, env=env).returncode  # the child's rank 0 writes the JSON line to our stdout
 
 
 def main():
@@ -184,6 +216,10 @@ def main():
         args.steps = 4 if lbl else 400
     if args.warmup is None:
         args.warmup = 1 if lbl else 20
+    if args.gpus < 1:
+        ap.error("--gpus must be >= 1")
+    if args.gpus > 1 and "RANK" not in os.environ:
+        sys.exit(self_launch(args.gpus))
 
     # stdout carries exactly ONE line, the JSON: libraries that print banners to fd 1 (RCCL does when its
     # communicator comes up) are sent to stderr until the result is ready
@@ -198,10 +234,7 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            sys.exit("launch with torch.distributed.run for --gpus > 1")
-        args.gpus = world
+    args.gpus = world  # under a launcher WORLD_SIZE rules (the driver passes the same number in both places)
 
     def log(msg):
         if rank == 0:

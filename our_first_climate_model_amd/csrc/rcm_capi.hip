@@ -43,6 +43,8 @@ struct rcm_ensemble {
   bool own_stream = false;
   bool have_grid = false, have_columns = false;
   long long step_index = 0;  // the reference's loop variable i (main.cpp:531)
+  bool img_valid = false;    // repwvl: d.img holds, for every column, the image of the most recent radiative transfer
+                             // (set by rcm_step; cleared by everything that changes what the image is made from)
   int user_chunks = 0;
   int fusion = -1;  // repwvl whole-step kernel k_step_repwvl: -1 automatic, 0 never, 1 always
   int exp_variant = 1, cube = 1, planck_fast = 1, pair = 1, flat = 1;
@@ -214,6 +216,7 @@ int classify_species(rcm_ensemble *h, const double *gas) {
   for (int j = 0; j < RCM_NSPEC_REPWVL; ++j) d.act_nibbles |= (unsigned long long)d.act[j] << (4 * j);
   // k_pre / k_post_wave write the coefficients of the active species only: everything else in the images is zero
   HIPCK(hipMemsetAsync(d.img, 0, (size_t)h->ncol * sizeof(rcm::RepwvlPairLds), h->stream));
+  h->img_valid = false;
   bool changed = old_set != h->shared_set;
   for (int s = 0; !changed && s < RCM_NSPEC_REPWVL; ++s)
     if ((h->shared_set >> s) & 1u)
@@ -258,7 +261,8 @@ constexpr int kPostSlices = 32;  // blocks per column of the first-stage chunk s
 
 bool use_flat(const rcm_ensemble *h) {
   return h->mode == rcm::MODE_REPWVL && h->flat && h->pair && h->exp_variant == 1 && h->user_chunks == 0 &&
-         h->d.n_wvl >= 8;  // at most 127/8 + 2 = 17 column images per block (45 KB)
+         h->d.n_wvl >= 8;  // at most 127/8 + 2 = 17 column images per block: 17 x 3 792 B + 22.5 KB staging = 87 KB of LDS
+                           // (one block per CU; n_wvl >= 22 -> 7 images, 49 KB: three blocks per CU; 100 -> 3 images, 34 KB)
 }
 
 #ifdef RCM_WITH_VARIANTS
@@ -640,6 +644,7 @@ int rcm_set_grid(rcm_ensemble *h, const double *plevel_hPa) {
   HIPCK(hipMemcpyAsync((void *)h->d.conv, h->conv.data(), NL * sizeof(double), hipMemcpyHostToDevice, h->stream));
   HIPCK(hipStreamSynchronize(h->stream));
   h->have_grid = true;
+  h->img_valid = false;
   return derive_repwvl_layers(h);
 }
 
@@ -666,6 +671,7 @@ int rcm_set_column_forcing(rcm_ensemble *h, const double *solar_irr, const int *
   if (cloud_tau)
     HIPCK(hipMemcpyAsync((void *)h->d.cloud_tau, cloud_tau, n * sizeof(double), hipMemcpyHostToDevice, h->stream));
   HIPCK(hipStreamSynchronize(h->stream));
+  h->img_valid = false;  // the cloud row is part of the stored column images (k_pre rewrites them at the next step)
   return RCM_OK;
 }
 
@@ -694,6 +700,7 @@ int rcm_solar_setup_columns(rcm_ensemble *h, const double *tau_s, const double *
   if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
   (void)hipFree(buf);
   if (e != hipSuccess) return fail(RCM_ERR_HIP, std::string("rcm_solar_setup_columns: ") + hipGetErrorString(e));
+  h->img_valid = false;  // k_solar rewrote the cloud optical depths
   return RCM_OK;
 }
 
@@ -737,6 +744,11 @@ int rcm_set_repwvl_tables(rcm_ensemble *h, int n_tpert, int n_species, int n_wvl
   if (h->mode != rcm::MODE_NONE) return fail(RCM_ERR_STATE, "rcm_set_repwvl_tables: tables already set");
   if ((unsigned long long)n_tpert * n_species * n_p * n_wvl * sizeof(double) >= (1ull << 32))
     return fail(RCM_ERR_ARG, "rcm_set_repwvl_tables: the table must stay below 4 GiB (32-bit offsets in the kernel)");
+  // ... and so must the table the production kernels really address: xp[layer][T bracket][species][wavelength][2],
+  // through `unsigned xoff + w*16 + species*n_wvl*16` (repwvl_pair_tau); for n_p < 36 it is the larger of the two
+  if ((unsigned long long)NL * (n_tpert - 1) * n_species * n_wvl * 2 * sizeof(double) >= (1ull << 32))
+    return fail(RCM_ERR_ARG, "rcm_set_repwvl_tables: the pressure-interpolated table (20 layers x (n_tpert-1) x 9 x n_wvl "
+                             "x 16 B) must stay below 4 GiB (32-bit offsets in the kernel)");
   if (int rc = use_device(h)) return rc;
   Dev &d = h->d;
   // re-lay out [t][s][w][p] -> [t][s][p][w] so that a wave's 64 wavelengths are contiguous
@@ -860,6 +872,7 @@ int rcm_set_columns(rcm_ensemble *h, const double *Tlayer0, const double *T_surf
   HIPCK(hipStreamSynchronize(h->stream));
   h->step_index = 0;
   h->have_columns = true;
+  h->img_valid = false;
   return RCM_OK;
 }
 
@@ -890,6 +903,8 @@ int rcm_step(rcm_ensemble *h, int nsteps) {
     if (int rc = ensure_partials(h)) return rc;
   for (int i = 0; i < nsteps; ++i)
     if (int rc = launch_step(h, i > 0, i + 1 < nsteps)) return rc;
+  // the last k_post of a call does not go on with the next iteration: d.img is the image of the last sweep
+  if (nsteps > 0) h->img_valid = h->mode == rcm::MODE_REPWVL;
   return RCM_OK;
 }
 
@@ -1003,7 +1018,18 @@ int rcm_get_tau_production(rcm_ensemble *h, int col, double *tau) {
   const size_t n = (size_t)h->d.nspec * NL;
   double *buf = nullptr;
   HIPCK(hipMalloc((void **)&buf, n * sizeof(double)));
-  hipLaunchKernelGGL(rcm::k_tau_pair, dim3((h->d.nspec + 31) / 32), dim3(64), 0, h->stream, h->d, col, buf);
+  if (use_flat(h)) {
+    // what k_rt_repwvl_flat reads: the image stored in d.img (k_pre / post_column; here k_image when no step has
+    // written it since the inputs last changed), copied, and the instantiation launch_rt_pair picks
+    if (!h->img_valid)
+      hipLaunchKernelGGL(rcm::k_image, dim3(1), dim3(64), 0, h->stream, h->d, col, h->step_index > 0 ? 1 : 0);
+    const int na = h->d.nact;
+    const auto kern = na <= 2 ? rcm::k_tau_img<2> : na <= 3 ? rcm::k_tau_img<3> : na <= 4 ? rcm::k_tau_img<4>
+                    : na <= 5 ? rcm::k_tau_img<5> : na <= 7 ? rcm::k_tau_img<7> : rcm::k_tau_img<9>;
+    hipLaunchKernelGGL(kern, dim3((h->d.nspec + 31) / 32), dim3(64), 0, h->stream, h->d, col, buf);
+  } else {
+    hipLaunchKernelGGL(rcm::k_tau_pair, dim3((h->d.nspec + 31) / 32), dim3(64), 0, h->stream, h->d, col, buf);
+  }
   hipError_t e = hipGetLastError();
   if (e == hipSuccess) e = hipMemcpyAsync(tau, buf, n * sizeof(double), hipMemcpyDeviceToHost, h->stream);
   if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
@@ -1150,6 +1176,7 @@ int rcm_checkpoint_load(rcm_ensemble *h, const char *path) {
   std::fclose(f);
   h->step_index = hdr[4];
   h->have_columns = true;
+  h->img_valid = false;  // (classify_species cleared the images; the next step or the optical-depth getter rebuilds them)
   return RCM_OK;
 }
 

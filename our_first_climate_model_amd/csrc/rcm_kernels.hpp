@@ -1806,10 +1806,11 @@ __global__ __launch_bounds__(64) void k_tau(Dev d, int col, double *out) {
   }
 }
 
-// The optical depths AS THE PRODUCTION KERNELS FORM THEM (rcm_get_tau_production): the same column image
-// (lbl_pair_image / repwvl_pair_image: T bracket, numDens-folded corner weights) and the same per-point
-// function (lbl_pair_tau / repwvl_pair_tau: weighted-corner sum, cloud, clamp) that k_rt_lbl_pair,
-// k_rt_repwvl_pair and k_rt_repwvl_flat call, on the same lane-pair layout; one wave per 32 points.
+// The optical depths AS THE PRODUCTION KERNELS FORM THEM (rcm_get_tau_production), lbl and the chunked repwvl
+// kernel (n_wvl < 8 or a pinned chunk count): the same column image (lbl_pair_image / repwvl_pair_image: T bracket,
+// numDens-folded corner weights, built in place) and the same per-point function (lbl_pair_tau / repwvl_pair_tau:
+// weighted-corner sum, cloud, clamp) that k_rt_lbl_pair and k_rt_repwvl_pair call, on the same lane-pair layout;
+// one wave per 32 points.  The flattened repwvl kernel copies a STORED image instead: k_image / k_tau_img below.
 __global__ __launch_bounds__(64) void k_tau_pair(Dev d, int col, double *out) {
   __shared__ union {
     PairLds lbl;
@@ -1831,6 +1832,37 @@ __global__ __launch_bounds__(64) void k_tau_pair(Dev d, int col, double *out) {
     const LblAddr ad = lbl_pair_addr(d, p);
     lbl_pair_tau(img.lbl, p, ad.sbase, ad.row0 + (unsigned)b * 8u, ad.rstep, st, lane);
   }
+  for (int k = 0; k < NH; ++k) out[(size_t)b * NL + (p ? NL - 1 - k : k)] = st[k][lane];
+}
+
+// rcm_get_tau_production on the flattened repwvl path: the image k_rt_repwvl_flat really copies.
+// k_image: (re)stores the image of ONE column for the optical depths of the most recent radiative transfer -- before
+// the first step: the one it will use -- through repwvl_image_store, the coefficient code of k_pre / post_column
+// (needed only when no stepping kernel has written d.img since the last change of the inputs: before step 0, after
+// rcm_set_columns / a forcing change on a live handle, after rcm_checkpoint_load).  from_Ttau: the temperatures the
+// brackets are taken at are d.Ttau (a step has run) or d.T (step 0: the pre-adjustment profile, main.cpp:500).
+__global__ __launch_bounds__(64) void k_image(Dev d, int col, int from_Ttau) {
+  __shared__ double scr[3 * NL];
+  const int lane = threadIdx.x;
+  const size_t at = (size_t)col * NL + (lane < NL ? lane : 0);
+  const double T = d.T[at], midT = from_Ttau ? d.Ttau[at] : T;
+  const double h2o = d.gas[(size_t)col * d.ngas * NL + (lane < NL ? lane : 0)];
+  repwvl_image_store(d, col, lane, T, midT, d.Tsfc[col], h2o, scr);
+}
+
+// ... and the optical depths from it: repwvl_pair_image_copy of d.img[col] + repwvl_pair_tau<NACT> with the NACT the
+// launch picks (launch_rt_pair), on the lane-pair layout of the production kernel; one wave per 32 wavelengths.
+template <int NACT>
+__global__ __launch_bounds__(64) void k_tau_img(Dev d, int col, double *out) {
+  __shared__ __align__(16) RepwvlPairLds img;
+  __shared__ double st[NH + 1][64];
+  const int lane = threadIdx.x;
+  const int p = PairRw::parity(lane);
+  repwvl_pair_image_copy(d, col, lane, img);
+  __syncthreads();
+  const long b = (long)blockIdx.x * 32 + PairRw::index(lane);
+  if (b >= d.nspec) return;
+  repwvl_pair_tau<NACT>(d, img, p, (int)b, st, lane);
   for (int k = 0; k < NH; ++k) out[(size_t)b * NL + (p ? NL - 1 - k : k)] = st[k][lane];
 }
 

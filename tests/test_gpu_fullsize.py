@@ -318,6 +318,36 @@ def test_two_ranks_with_hip_compute_equal_one_rank(pkg, tmp_path):
     assert np.ptp(a[:, 20]) > 0.1  # the perturbed columns differ: a rank-order mix-up would show
 
 
+def test_bench_gpus_2_without_a_launcher_starts_its_own(pkg, tmp_path):
+    """`python bench.py --gpus 2 ...` with NO torch.distributed.run in front (the form the driver used for N = 1 in
+    round 2): bench.py starts the launcher itself as a child process before touching the GPU, the child's one JSON
+    line comes through on stdout, rc 0, and the gathered state equals the one-rank run."""
+    common = ["--ncol", "64", "--nodes", "4097", "--steps", "2", "--warmup", "0", "--no-cpu-baseline"]
+    one, two = str(tmp_path / "one.npy"), str(tmp_path / "two.npy")
+    d1 = _bench(common + ["--dump-state", one])
+    d2 = _bench(common + ["--gpus", "2", "--backend", "gloo", "--dump-state", two])   # nproc=None: no launcher
+    assert d1["n_gpus"] == 1 and d2["n_gpus"] == 2 and d2["config"]["columns_per_gpu"] == 32
+    a, b = np.load(one), np.load(two)
+    assert a.shape == b.shape == (64, 21) and np.isfinite(a).all()
+    assert H.max_abs(a, b) <= 1e-10
+    assert np.ptp(a[:, 20]) > 0.1
+
+
+def test_nccl_leg_with_the_one_rank_this_box_allows(pkg, tmp_path):
+    """The code the 8-GPU SCALE run executes -- init_process_group("nccl", device_id=...), the packed state
+    all-gathered ON DEVICE by RCCL, all_reduce(max) of the time -- with the one rank a one-GPU box can give RCCL:
+    rc 0, one JSON line, and the gathered [64][21] state BIT-IDENTICAL to the run without a launcher (same cut,
+    same chunking, so the same order of every sum)."""
+    common = ["--ncol", "64", "--nodes", "4097", "--steps", "2", "--warmup", "1", "--no-cpu-baseline"]
+    plain, nccl = str(tmp_path / "plain.npy"), str(tmp_path / "nccl.npy")
+    d0 = _bench(common + ["--dump-state", plain])
+    d1 = _bench(common + ["--gpus", "1", "--backend", "nccl", "--dump-state", nccl], nproc=1)
+    assert d0["n_gpus"] == d1["n_gpus"] == 1 and d1["config"]["columns_per_gpu"] == 64
+    assert d1["roofline"]["launches"] == 2 and d1["value"] > 0
+    a, b = np.load(plain), np.load(nccl)
+    assert a.shape == (64, 21) and np.array_equal(a, b)
+
+
 def test_repwvl_bench_workload_contract(pkg):
     d = _bench(["--workload", "repwvl100", "--ncol", "500", "--steps", "5", "--warmup", "1"])
     assert d["config"]["wavelengths"] == 100 and d["roofline"]["kernel"] == "k_rt_repwvl_flat"

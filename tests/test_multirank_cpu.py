@@ -139,3 +139,21 @@ def test_two_ranks_stop_on_the_global_residual(rcm, olib):
     assert [g[1] for g in got] == [done1, done1]
     assert got[0][2] == got[1][2] == worst1
     assert max(g[3] for g in got) == worst1  # the global value is the larger of the two local ones
+
+
+def test_bench_self_launch_reaches_every_rank_without_a_gpu():
+    """`python bench.py --gpus 2` with no launcher in front must start torch.distributed.run itself (VERDICT r02
+    item 2 / ADVICE r02): on this GPU-less container both ranks come up (RANK/WORLD_SIZE set by the child
+    launcher) and then fail LOUDLY at the product's "no CPU fallback" assertion -- rc != 0, no JSON line.  The
+    same command on the MI355X box is tests/test_gpu_fullsize.py::test_bench_gpus_2_without_a_launcher_starts_its_own."""
+    import subprocess
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present: the GPU test covers the real run")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo", "--ncol",
+                        "8", "--nodes", "257", "--steps", "1", "--warmup", "0", "--no-cpu-baseline"],
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode != 0
+    assert "torch.distributed.run" in r.stderr and "--nproc-per-node=2" in r.stderr
+    assert r.stderr.count("bench.py needs the MI355X (no CPU fallback)") >= 2, r.stderr[-3000:]
+    assert not [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
