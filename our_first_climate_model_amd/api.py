@@ -67,9 +67,6 @@ def _configure(L):
     L.rcm_pack_state.argtypes = [vp, vp]
     L.rcm_set_spectral_chunks.argtypes = [vp, C.c_int]
     L.rcm_get_spectral_chunks.argtypes = [vp]
-    if hasattr(L, "rcm_set_step_fusion"):  # test-side build only (-DRCM_WITH_VARIANTS): the fused repwvl step
-        L.rcm_set_step_fusion.argtypes = [vp, C.c_int]
-        L.rcm_get_step_fusion.argtypes = [vp]
     L.rcm_set_rt_timing.argtypes = [vp, C.c_int]
     L.rcm_get_rt_timing.argtypes = [vp, _dp, _ip]
     L.rcm_atm_load.argtypes = [C.c_char_p, C.c_int, _dp, _ip, _ip]
@@ -376,23 +373,6 @@ class Ensemble:
 
     def get_spectral_chunks(self):
         n = self._L.rcm_get_spectral_chunks(self.h)
-        if n < 0:
-            self._ck(n)
-        return n
-
-    def set_step_fusion(self, mode):
-        """TEST-SIDE build only: the fused whole-step repwvl kernel k_step_repwvl, 1 on / 0 or -1 off."""
-        if not hasattr(self._L, "rcm_set_step_fusion"):
-            if mode == 1:
-                raise RcmError(-1, "the fused repwvl step kernel exists in the test-side build only")
-            return
-        self._ck(self._L.rcm_set_step_fusion(self.h, mode))
-
-    def get_step_fusion(self):
-        """Lane pairs per column of the fused repwvl kernel in use; 0 = the three-kernel path (always, in the product)."""
-        if not hasattr(self._L, "rcm_get_step_fusion"):
-            return 0
-        n = self._L.rcm_get_step_fusion(self.h)
         if n < 0:
             self._ck(n)
         return n

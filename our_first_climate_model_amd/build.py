@@ -12,7 +12,7 @@ MAIN = os.path.join(PKG, "rcm_main")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 
 SOURCES = ["rcm_capi.hip", "rcm_host.cpp", "rcm_nc.cpp"]
-HEADERS = ["rcm_kernels.hpp", "rcm_device.hpp", "rcm_internal.hpp", "rcm_exp_coef.hpp"]
+HEADERS = ["rcm_kernels.hpp", "rcm_device.hpp", "rcm_internal.hpp", "rcm_exp_coef.hpp", "rcm_variants.hpp"]
 
 
 def _newer(target, deps):

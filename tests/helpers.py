@@ -43,3 +43,28 @@ def gpu_ensemble(pkg, inp, **kw):
 
 def max_abs(a, b):
     return float(np.max(np.abs(np.asarray(a) - np.asarray(b))))
+
+
+# ---- TEST-SIDE library only (tests/_variants/librcm_hip_variants.so, -DRCM_WITH_VARIANTS) --------------------------
+def set_step_fusion(e, mode):
+    """The fused whole-step repwvl kernel k_step_repwvl of the variants build: 1 on / 0 or -1 off.  The product
+    library has neither the kernel nor the entry point: asking it for mode 1 is an error, 0 / -1 a no-op."""
+    if not hasattr(e._L, "rcm_set_step_fusion"):
+        if mode == 1:
+            raise RuntimeError("the fused repwvl step kernel exists in the test-side build only")
+        return
+    import ctypes as C
+    e._L.rcm_set_step_fusion.argtypes = [C.c_void_p, C.c_int]
+    e._ck(e._L.rcm_set_step_fusion(e.h, mode))
+
+
+def get_step_fusion(e):
+    """Lane pairs per column of the fused repwvl kernel in use; 0 = the three-kernel path (always, in the product)."""
+    if not hasattr(e._L, "rcm_get_step_fusion"):
+        return 0
+    import ctypes as C
+    e._L.rcm_get_step_fusion.argtypes = [C.c_void_p]
+    n = e._L.rcm_get_step_fusion(e.h)
+    if n < 0:
+        e._ck(n)
+    return n

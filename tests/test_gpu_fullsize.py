@@ -43,7 +43,7 @@ def _columns(inp, idx):
 def _compare_sampled(pkg, olib, inp, idx, steps, library=None, fusion=-1):
     g = H.gpu_ensemble(pkg, inp, library=library)
     if fusion != -1:
-        g.set_step_fusion(fusion)
+        H.set_step_fusion(g, fusion)
     o = H.oracle_ensemble(olib, _columns(inp, idx))
     g.step(steps), o.step(steps)
     fg, fo, sg, so = g.get_fluxes(), o.get_fluxes(), g.get_state(), o.get_state()
@@ -74,7 +74,7 @@ def test_config2_10000_columns_reduced100_sampled_against_oracle(pkg, olib, vari
     inp = H.make_inputs(pkg, "repwvl", 10000, table="Reduced100")
     idx = [0, 1, 2, 3, 3333, 4999, 5000, 7777, 9996, 9997, 9998, 9999]  # incl. the first and the last block
     g = H.gpu_ensemble(pkg, inp)
-    assert g.get_step_fusion() == 0 and g.get_spectral_chunks() == 5  # flattened kernel, 5 record slots per column
+    assert H.get_step_fusion(g) == 0 and g.get_spectral_chunks() == 5  # flattened kernel, 5 record slots per column
     g.close()
     _compare_sampled(pkg, olib, inp, idx, steps=2)
     _compare_sampled(pkg, olib, inp, idx, steps=2, library=variants, fusion=1)
@@ -112,8 +112,8 @@ def test_fused_step_kernel_against_oracle_ragged_sizes(pkg, olib, variants, tabl
         inp = H.make_inputs(pkg, "repwvl", ncol, table=table)
         inp["cols"]["Tlayer0"][ncol // 2, 15] += 25.0  # one unstable column: the sort reorders its layers
         g, o = H.gpu_ensemble(pkg, inp, library=variants), H.oracle_ensemble(olib, inp)
-        g.set_step_fusion(1)
-        seen.add(g.get_step_fusion())
+        H.set_step_fusion(g, 1)
+        seen.add(H.get_step_fusion(g))
         g.step(1), o.step(1)
         for k, v in o.get_fluxes().items():
             assert H.max_abs(g.get_fluxes()[k], v) <= FLUX_TIGHT, (ncol, k)
@@ -142,12 +142,12 @@ def test_fused_and_three_kernel_paths_agree_and_interleave(pkg, olib, variants, 
     inp = H.make_inputs(pkg, "repwvl", 9, table="Reduced20")
     a, c = (H.gpu_ensemble(pkg, inp, library=variants) for _ in range(2))
     b = H.gpu_ensemble(pkg, inp)  # the product: three kernels per iteration, nothing else to select
-    a.set_step_fusion(1)
-    assert a.get_step_fusion() > 0 and b.get_step_fusion() == 0 and c.get_step_fusion() == 0  # automatic = off
+    H.set_step_fusion(a, 1)
+    assert H.get_step_fusion(a) > 0 and H.get_step_fusion(b) == 0 and H.get_step_fusion(c) == 0  # automatic = off
     with pytest.raises(pkg.RcmError):
-        b.set_step_fusion(1)
+        H.set_step_fusion(b, 1)
     a.step(6), b.step(6)
-    c.set_step_fusion(1), c.step(2), c.set_step_fusion(0), c.step(3), c.set_step_fusion(1), c.step(1)
+    H.set_step_fusion(c, 1), c.step(2), H.set_step_fusion(c, 0), c.step(3), H.set_step_fusion(c, 1), c.step(1)
     for x in (b, c):
         for k, v in a.get_fluxes().items():
             assert H.max_abs(x.get_fluxes()[k], v) <= FLUX_TIGHT, k
@@ -157,7 +157,7 @@ def test_fused_and_three_kernel_paths_agree_and_interleave(pkg, olib, variants, 
     a.checkpoint_save(ck)
     d = H.gpu_ensemble(pkg, inp, library=variants)
     d.checkpoint_load(ck)
-    d.set_step_fusion(1)
+    H.set_step_fusion(d, 1)
     a.step(600), d.step(600)
     np.testing.assert_array_equal(a.get_state()["Tlayer"], d.get_state()["Tlayer"])  # resume is bit-identical
     o = H.oracle_ensemble(olib, inp)
@@ -169,13 +169,13 @@ def test_fused_and_three_kernel_paths_agree_and_interleave(pkg, olib, variants, 
 def test_fused_equilibrium_and_nan_column(pkg, olib, variants):
     inp = H.make_inputs(pkg, "repwvl", 6, table="Reduced10")
     g, o = H.gpu_ensemble(pkg, inp, library=variants), H.oracle_ensemble(olib, inp)
-    g.set_step_fusion(1)
+    H.set_step_fusion(g, 1)
     n_g, r_g = g.run_to_equilibrium(0.12, 400, 25)
     n_o, r_o = o.run_to_equilibrium(0.12, 400, 25)
     assert n_g == n_o and 25 <= n_g < 400 and abs(r_g - r_o) <= 1e-9
     inp["cols"]["Tlayer0"][4, 3] = np.nan
     g = H.gpu_ensemble(pkg, inp, library=variants)
-    g.set_step_fusion(1)
+    H.set_step_fusion(g, 1)
     g.step(3)
     s = g.get_state()
     assert np.isnan(s["Tlayer"][4]).all() and np.isnan(s["T_surface"][4]) and np.isnan(g.get_residual()[4])
@@ -216,6 +216,98 @@ def test_production_tau_interpolation_against_read_tau(pkg, olib, table):
     g.step(3), o.step(3)
     for c in (0, 1):  # (the extrapolating columns have negative optical depths somewhere: NaN after a step)
         np.testing.assert_allclose(g.get_tau_production(c), o.get_tau(c), rtol=1e-12, atol=0)
+
+
+def test_production_tau_comes_from_the_stored_column_images(pkg, olib, tmp_path):
+    """The flattened repwvl kernel COPIES the image repwvl_image_store wrote to d.img (k_pre / post_column; active
+    species only, the rest zero since the memset) and runs repwvl_pair_tau<NACT> with NACT < 9; the chunked kernel
+    builds its image in place (repwvl_pair_image_from, all 9 species).  rcm_get_tau_production follows whichever
+    the launch would take: here both routes, on a live handle whose species pattern changes,
+    after a cloud change between steps, and after rcm_checkpoint_load -- each <= 1e-12 from read_tau, and the two
+    routes BIT-identical to each other (the species a smaller NACT skips contribute fma(0, x, a) = a)."""
+    rng = np.random.default_rng(3)
+    inp = H.make_inputs(pkg, "repwvl", 9, table="Reduced20")
+    g, o = H.gpu_ensemble(pkg, inp), H.oracle_ensemble(olib, inp)
+
+    def both_routes(tag):
+        for c in (0, 4, 8):
+            stored = g.get_tau_production(c)          # flat: k_image (if needed) + copy of d.img + NACT of the launch
+            g.set_spectral_chunks(2)                  # a pinned chunk count selects k_rt_repwvl_pair: image built in place
+            in_place = g.get_tau_production(c)
+            g.set_spectral_chunks(0)
+            assert np.array_equal(stored, in_place), (tag, c)
+            np.testing.assert_allclose(stored, o.get_tau(c), rtol=1e-12, atol=0, err_msg=tag)
+
+    both_routes("before the first step")
+    g.step(3), o.step(3)
+    both_routes("after 3 steps")                      # d.img as post_column / k_pre left it
+    # a cloud change between steps: the getter shows the new cloud at once (as the oracle's does)
+    tau_c = np.linspace(0.2, 1.8, 9)
+    lay = np.array([17, 16, 15, -1, 3, 17, 0, 19, 10], dtype=np.int32)
+    g.set_column_forcing(cloud_layer=lay, cloud_tau=tau_c), o.set_column_forcing(cloud_layer=lay, cloud_tau=tau_c)
+    both_routes("after a forcing change")
+    g.step(2), o.step(2)
+    both_routes("2 steps later")
+    # checkpoint -> a fresh handle: classify_species clears the images, the getter rebuilds from Ttau and the gas block
+    path = str(tmp_path / "img.ckpt")
+    g.checkpoint_save(path)
+    want = [g.get_tau_production(c) for c in range(9)]
+    b = pkg.Ensemble(9)
+    b.set_grid(inp["cols"]["plevel"])
+    b.set_repwvl_tables(inp["table"])
+    b.checkpoint_load(path)
+    for c in range(9):
+        assert np.array_equal(b.get_tau_production(c), want[c]), c
+    b.step(2), g.step(2), o.step(2)
+    for c in range(9):
+        assert np.array_equal(b.get_tau_production(c), g.get_tau_production(c)), c
+    both_routes("after the resumed steps")
+    # another species pattern on the live handle: CH4 now varies, O3 doubled; N2O alone stays shared -> no merged slot
+    gas = inp["cols"]["gas"]
+    gas[:, 5] *= rng.uniform(0.5, 2.0, (9, 1))
+    gas[:, 2] *= 2.0
+    gas[:, 3] *= rng.uniform(0.5, 2.0, (9, 1))
+    c_ = inp["cols"]
+    g.set_columns(c_["Tlayer0"], c_["T_surface0"], c_["gas"], c_["rel_hum"])
+    o = H.oracle_ensemble(olib, inp)
+    o.set_column_forcing(cloud_layer=lay, cloud_tau=tau_c)   # (the handle keeps its forcing across rcm_set_columns)
+    both_routes("new species pattern")
+    g.step(2), o.step(2)
+    both_routes("new species pattern, stepped")
+    fg, fo = g.get_fluxes(), o.get_fluxes()
+    for k in fg:
+        assert H.max_abs(fg[k], fo[k]) <= FLUX_TIGHT, k
+
+
+def test_production_tau_of_a_table_with_fewer_than_8_wavelengths(pkg, olib):
+    """n_wvl < 8 keeps the chunked kernel (17 column images per block would not pay): the getter takes the
+    in-place image route there, against read_tau to 1e-12, and the fluxes agree."""
+    inp = H.make_inputs(pkg, "repwvl", 5, table="Reduced10")
+    t = dict(inp["table"])
+    t["n_wvl"] = 5
+    t["wvl"], t["weight"] = t["wvl"][:5].copy(), t["weight"][:5].copy()
+    t["xsec"] = np.ascontiguousarray(t["xsec"][:, :, :5, :])
+    inp["table"] = t
+    g, o = H.gpu_ensemble(pkg, inp), H.oracle_ensemble(olib, inp)
+    g.step(2), o.step(2)
+    for c in range(5):
+        np.testing.assert_allclose(g.get_tau_production(c), o.get_tau(c), rtol=1e-12, atol=0)
+    fg, fo = g.get_fluxes(), o.get_fluxes()
+    for k in fg:
+        assert H.max_abs(fg[k], fo[k]) <= FLUX_TIGHT, k
+
+
+def test_repwvl_table_whose_derived_layers_would_overflow_32_bit_offsets_is_refused(pkg):
+    """the kernels address xp[20][n_tpert-1][9][n_wvl][2] through 32-bit byte offsets; a table that passes
+    the raw 4 GiB check but whose pressure-interpolated form does not (few pressures, many wavelengths) is refused."""
+    n_t, n_p, n_w = 9, 3, 190000          # raw: 9*9*3*190000*8 = 0.37 GB; derived: 20*8*9*190000*16 = 4.4 GB
+    t = dict(n_tpert=n_t, n_species=9, n_wvl=n_w, n_p=n_p, p_grid=np.array([1.1e5, 5e4, 1e2]),
+             t_ref=np.array([288.0, 250.0, 220.0]), t_pert=np.linspace(-120, 120, n_t),
+             wvl=np.linspace(4000.0, 1e5, n_w), weight=np.ones(n_w), xsec=np.zeros((n_t, 9, n_w, n_p)))
+    e = pkg.Ensemble(1)
+    with pytest.raises(pkg.RcmError) as ei:
+        e.set_repwvl_tables(t)
+    assert ei.value.code == -1 and "pressure-interpolated table" in str(ei.value)
 
 
 def test_production_tau_outside_the_pressure_grid_measured_bound(pkg, olib):

@@ -36,7 +36,7 @@ ens = {}
 for name, L in libs.items():
     g = H.gpu_ensemble(pkg, inp, library=L)
     r = H.gpu_ensemble(pkg, inr, library=L)
-    r.set_step_fusion(0)
+    H.set_step_fusion(r, 0)
     g.step(1), r.step(20)
     g.sync(), r.sync()
     g.set_rt_timing(True), r.set_rt_timing(True)
@@ -53,4 +53,4 @@ print(f"== kernel time: lbl {ncol} columns x 131071 bands per launch; repwvl 100
 for name in libs:
     a, b = np.array(tl[name]), np.array(tr[name])
     print(f"{name:14s} lbl median {np.median(a):8.3f} ms (min {a.min():8.3f})   repwvl median {np.median(b) * 1e3:7.1f} us "
-          f"(min {b.min() * 1e3:7.1f})  fusion={ens[name][1].get_step_fusion()}", flush=True)
+          f"(min {b.min() * 1e3:7.1f})  fusion={H.get_step_fusion(ens[name][1])}", flush=True)

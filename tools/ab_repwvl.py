@@ -27,7 +27,7 @@ ens = {}
 for name, L in libs.items():
     for cname, fusion, lpc in cases:
         g = H.gpu_ensemble(pkg, inp, library=L)
-        g.set_step_fusion(fusion)
+        H.set_step_fusion(g, fusion)
         ens[(name, cname)] = (g, lpc)
 import time
 times = {k: [] for k in ens}

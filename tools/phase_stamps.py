@@ -22,7 +22,7 @@ L.rcm_dbg_stamps.argtypes = [C.c_void_p, C.POINTER(C.c_ulonglong), C.c_int]
 inp = H.make_inputs(pkg, "repwvl", ncol, table="Reduced100")
 g = H.gpu_ensemble(pkg, inp, library=L)
 if mode == "flat":
-    g.set_step_fusion(0)
+    H.set_step_fusion(g, 0)
     nblocks = (ncol * 100 + 127) // 128
     nsamp = (nblocks + 60) // 61
     buf = np.zeros(nsamp * 64, dtype=np.uint64)
@@ -38,8 +38,8 @@ if mode == "flat":
         dd = s[:, b] - s[:, a]
         print(f"  {n:26s} {np.median(dd):9.0f} {np.percentile(dd, 10):9.0f} {np.percentile(dd, 90):9.0f}")
     sys.exit(0)
-g.set_step_fusion(1)
-lpc = g.get_step_fusion()
+H.set_step_fusion(g, 1)
+lpc = H.get_step_fusion(g)
 nwaves = (ncol + 32 // lpc - 1) // (32 // lpc)
 nsamp = (nwaves + 60) // 61
 buf = np.zeros(nsamp * 64, dtype=np.uint64)

@@ -22,7 +22,7 @@ inp = H.make_inputs(pkg, "repwvl", ncol, table=table)
 nw = inp["table"]["n_wvl"]
 for name, fusion, chunks in (("fused", 1, 0), ("flat", 0, 0), ("chunked", 0, 1)):
     g = H.gpu_ensemble(pkg, inp, library=VLIB if fusion == 1 else None)
-    g.set_step_fusion(fusion)
+    H.set_step_fusion(g, fusion)
     if chunks:
         g.set_spectral_chunks(chunks)
     g.step(20)
@@ -35,5 +35,5 @@ for name, fusion, chunks in (("fused", 1, 0), ("flat", 0, 0), ("chunked", 0, 1))
     ms, n = g.get_rt_timing()
     print(f"{table} ncol={ncol} {name:8s}: {dt / steps * 1e3:.4f} ms/step wall, kernel {ms / steps:.4f} ms/step ({n} launches), "
           f"{ncol * steps / dt / 1e6:.2f} M column-timesteps/s, {ncol * nw / (ms / steps) / 1e6:.2f} Gpoint/s, "
-          f"lane pairs/column={g.get_step_fusion()}", flush=True)
+          f"lane pairs/column={H.get_step_fusion(g)}", flush=True)
     g.close()
