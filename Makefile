@@ -2,6 +2,7 @@
 #   make            -> our_first_climate_model_amd/librcm_hip.so + our_first_climate_model_amd/rcm_main
 #   make examples   -> examples/abi_minimal (the C ABI from a plain C++ program)
 #   make oracle     -> the CPU checker (test infrastructure, never linked into the product)
+#   make asan-nc    -> mutation fuzz of the .nc reader under ASan/UBSan (100 000 cases, host code)
 # `python -m our_first_climate_model_amd.build` does the same from Python (and is what __graft_entry__.build() calls).
 HIPCC     ?= /opt/rocm/bin/hipcc
 ROCM_PATH ?= /opt/rocm
@@ -32,7 +33,14 @@ $(MAIN): $(CSRC)/rcm_main.cpp $(LIB) include/rcm.h
 oracle:
 	$(MAKE) -C oracle
 
+# The HDF5-subset reader under ASan + UBSan on mutated tables (host code; tests/test_sanitize_nc.py runs 4 000 cases)
+asan-nc:
+	g++ -std=c++17 -O1 -g -fsanitize=address,undefined -fno-sanitize-recover=all -fno-omit-frame-pointer -Iinclude \
+	  -I$(CSRC) -o /tmp/rcm_nc_fuzz tests/sanitize/nc_fuzz.cpp $(CSRC)/rcm_nc.cpp $(CSRC)/rcm_host.cpp
+	/tmp/rcm_nc_fuzz tests/golden/Reduced10Forcing.nc 100000 /tmp/rcm_nc_fuzz_scratch.nc \
+	  $(wildcard /root/reference/repwvl_V2.01_cpp/Reduced20Forcing.nc /root/reference/repwvl_V2.01_cpp/Reduced100Forcing.nc)
+
 clean:
 	rm -f $(LIB) $(MAIN) examples/abi_minimal
 
-.PHONY: all examples oracle clean
+.PHONY: all examples oracle asan-nc clean

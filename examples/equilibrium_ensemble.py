@@ -11,6 +11,10 @@ all-gather of (Tlayer[20], T_surface) ends the run.
     python examples/equilibrium_ensemble.py --ncol 100000 --shard 3/8 --tol 0.01 --max-steps 1500   (rehearsal: the
         block of rank 3 of 8 alone on one GPU, no collective; tools/eq100k_shards.sh runs all eight that way)
 
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 \\
+        examples/equilibrium_ensemble.py --backend gloo --ncol 16 --nodes 1025      (two ranks on ONE GPU: the
+        collectives run on CPU tensors over gloo -- RCCL does not take two ranks on one device; tests do this)
+
 Needs an MI355X per rank (the product has no CPU path).  Spectra are the seeded synthetic stand-in for the
 absent lbl.*.asc files (our_first_climate_model_amd.synth_lbl_tables)."""
 import argparse
@@ -34,6 +38,11 @@ def main():
     ap.add_argument("--shard", default=None, metavar="R/W",
                     help="rehearsal without a collective: integrate the block of rank R of W alone in this process")
     ap.add_argument("--save-state", default=None, help="write the [columns][21] result of this process to a .npy file")
+    ap.add_argument("--backend", default="nccl", choices=("nccl", "gloo"),
+                    help="torch.distributed backend; gloo (collectives on CPU tensors) to run several ranks on one GPU")
+    ap.add_argument("--nan-column", type=int, default=None, metavar="C",
+                    help="fault injection: column C of the whole ensemble starts with a NaN surface temperature; it "
+                         "must keep EVERY rank from reporting convergence (the NaN flag of the all-reduce)")
     a = ap.parse_args()
 
     import numpy as np
@@ -52,12 +61,17 @@ def main():
     torch.cuda.set_device(dev)
     if "RANK" in os.environ:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", dev))
+        if a.backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", dev))
+        else:
+            dist.init_process_group("gloo")
 
     lo, hi = shard_bounds(a.ncol, *shard) if shard else shard_bounds(a.ncol, rank, world)
     atm, _ = rcm.atm_load(os.path.join(ROOT, "tests", "golden", "fpda.lbl.atm"))
     spec = rcm.perturbation_sweep(hi - lo, perturb_rh=True, perturb_ts=True, first=lo, total=a.ncol)
     cols = rcm.build_columns(atm, spec, "lbl")
+    if a.nan_column is not None and lo <= a.nan_column < hi:
+        cols["T_surface0"][a.nan_column - lo] = float("nan")
     wvl, tabs = rcm.synth_lbl_tables(a.nodes, plevel=cols["plevel"])
     inp = dict(mode="lbl", ncol=hi - lo, cols=cols, solar=rcm.default_solar()["solar_irr"], wvl=wvl, tabs=tabs)
     ens = rcm.configure(rcm.Ensemble(hi - lo, device=dev, stream=torch.cuda.current_stream().cuda_stream), inp)
@@ -73,7 +87,8 @@ def main():
     packed = torch.empty((hi - lo, 21), dtype=torch.float64, device="cuda")
     ens.pack_state(packed.data_ptr())
     ens.sync()
-    full = packed if shard else gather_state(packed, a.ncol, world, dist)
+    on_cpu = dist.is_initialized() and a.backend == "gloo"
+    full = packed if shard else gather_state(packed.cpu() if on_cpu else packed, a.ncol, world, dist)
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     if a.save_state and rank == 0:
@@ -86,7 +101,7 @@ def main():
             "steps": steps, "converged": bool(resid <= a.tol), "residual_K_per_step": resid, "tol_K": a.tol,
             "seconds": elapsed, "column_timesteps_per_sec": (hi - lo if shard else a.ncol) * steps / elapsed,
             "T_surface_K": {"min": float(ts.min()), "median": float(np.median(ts)), "max": float(ts.max())},
-            "all_finite": bool(torch.isfinite(full).all())}))
+            "all_finite": bool(torch.isfinite(full).all()), "ranks": world, "backend": a.backend if world > 1 else None}))
     if dist.is_initialized():
         dist.barrier()
         dist.destroy_process_group()

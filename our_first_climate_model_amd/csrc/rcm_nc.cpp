@@ -44,7 +44,9 @@ struct H5 {
     for (int i = n - 1; i >= 0; --i) v = (v << 8) | buf[pos + i];
     return v;
   }
-  bool sig(uint64_t pos, const char *s) const { return pos + 4 <= buf.size() && std::memcmp(&buf[pos], s, 4) == 0; }
+  bool sig(uint64_t pos, const char *s) const {  // (pos may be any 64-bit value from the file: no pos + 4, it can wrap)
+    return pos <= buf.size() && buf.size() - pos >= 4 && std::memcmp(&buf[pos], s, 4) == 0;
+  }
   bool undef(uint64_t a) const { return so == 8 ? a == ~0ull : a == ((1ull << (8 * so)) - 1); }
 };
 

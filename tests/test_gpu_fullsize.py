@@ -440,11 +440,62 @@ def test_nccl_leg_with_the_one_rank_this_box_allows(pkg, tmp_path):
     assert a.shape == (64, 21) and np.array_equal(a, b)
 
 
+def _equilibrium_example(args, nproc=None, port=29641, timeout=900):
+    cmd = [sys.executable]
+    if nproc:
+        cmd += ["-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={nproc}", "--master-addr", "127.0.0.1",
+                "--master-port", str(port)]
+    cmd += [os.path.join(H.ROOT, "examples", "equilibrium_ensemble.py"), "--progress", "0"] + args
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    return json.loads(lines[0])
+
+
+def test_equilibrium_stop_rule_across_two_ranks_with_hip_compute(pkg, tmp_path):
+    """BASELINE configs[4]'s multi-rank path with HIP compute: examples/equilibrium_ensemble.py
+    as two torch.distributed.run ranks on this box's one GPU (gloo: collectives on CPU tensors), each integrating its
+    8 of 16 columns on the lbl kernels, distributed.run_to_equilibrium's all-reduce(max) of the residual keeping them
+    on one iteration count.  Against the one-rank run of the same 16 columns: the SAME number of steps, the residual
+    equal to 1e-9, the gathered state to 1e-10 K (another cut = another fixed order of the spectral sums), converged.
+    Then a NaN column on rank 1 only: neither rank may report convergence (the NaN travels as a flag: max() is not
+    NaN-propagating in every backend) and both run to max_steps."""
+    common = ["--ncol", "16", "--nodes", "1025", "--tol", "0.05", "--check-every", "10", "--max-steps", "1500"]
+    one, two = str(tmp_path / "one.npy"), str(tmp_path / "two.npy")
+    d1 = _equilibrium_example(common + ["--save-state", one])
+    d2 = _equilibrium_example(common + ["--backend", "gloo", "--save-state", two], nproc=2)
+    assert d1["converged"] and d2["converged"] and d2["ranks"] == 2 and d2["backend"] == "gloo"
+    assert d1["steps"] == d2["steps"] and 100 <= d1["steps"] < 1500 and d1["steps"] % 10 == 0
+    assert abs(d1["residual_K_per_step"] - d2["residual_K_per_step"]) <= 1e-9 and d2["residual_K_per_step"] <= 0.05
+    a, b = np.load(one), np.load(two)
+    assert a.shape == b.shape == (16, 21) and np.isfinite(a).all() and H.max_abs(a, b) <= 1e-10
+    assert np.all((a[:, 20] > 280.0) & (a[:, 20] < 320.0)) and np.ptp(a[:, 20]) > 0.1
+    # column 12 lives on rank 1; rank 0's own columns all converge, the run must not
+    d3 = _equilibrium_example(["--ncol", "16", "--nodes", "1025", "--tol", "1e9", "--check-every", "5", "--max-steps",
+                               "20", "--backend", "gloo", "--nan-column", "12", "--save-state", two], nproc=2, port=29643)
+    assert not d3["converged"] and d3["steps"] == 20 and d3["residual_K_per_step"] != d3["residual_K_per_step"]
+    c = np.load(two)
+    assert np.isnan(c[12]).all() and np.isfinite(np.delete(c, 12, axis=0)).all()
+    d4 = _equilibrium_example(["--ncol", "16", "--nodes", "1025", "--tol", "1e9", "--check-every", "5", "--max-steps",
+                               "20", "--backend", "gloo"], nproc=2, port=29645)
+    assert d4["converged"] and d4["steps"] == 5       # the same run without the NaN stops at the first check
+
+
 def test_repwvl_bench_workload_contract(pkg):
     d = _bench(["--workload", "repwvl100", "--ncol", "500", "--steps", "5", "--warmup", "1"])
     assert d["config"]["wavelengths"] == 100 and d["roofline"]["kernel"] == "k_rt_repwvl_flat"
     assert d["roofline"]["launches"] == 5
     assert d["roofline"]["algorithmic_bytes_per_launch"] == (9 * 9 * 41 * 8 + 16) * 100 * 500
+    # the nominal numerator never crosses HBM for this workload (the 2.66 MB table lives in L2): a fraction above 1 is
+    # not a roofline, so the machine-read line says null and why, and carries the two fractions that are measured
+    r = d["roofline"]
+    assert r["frac"] is None and "frac is null on purpose" in r["note"] and r["achieved"] > 0
+    assert "hbm_traffic_frac" in r and "actual_frac" in r and r["actual_bound"].startswith("fp64_valu_issue+")
+    if r["fp64_valu_issue"] is not None:   # counters of THIS kernel build are committed
+        assert r["actual_frac"] == r["fp64_valu_issue"]["issue_frac_at_2.4GHz"] and 0.0 < r["actual_frac"] <= 1.0
+    else:
+        assert r["actual_frac"] is None
     assert d["cpu_baseline"]["kind"] == "port" and d["cpu_baseline"]["single_core_rt_only_value"] > 0
     assert d["cpu_baseline"]["single_core_reread_table_per_step_value"] < d["cpu_baseline"]["single_core_value"]
 

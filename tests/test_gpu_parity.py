@@ -555,8 +555,12 @@ def test_bench_contract_on_a_small_workload(pkg):
               "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
         assert k in d, k
     assert d["n_gpus"] == 1 and d["steps"] == 2 and d["dtype"] == "f64" and d["vs_baseline"] is None
-    assert set(("bound", "achieved", "peak", "unit", "frac", "traffic")) <= set(d["roofline"])
+    assert set(("bound", "achieved", "peak", "unit", "frac", "traffic", "hbm_traffic_frac", "actual_frac",
+                "actual_bound")) <= set(d["roofline"])
     assert abs(d["roofline"]["frac"] - d["roofline"]["achieved"] / d["roofline"]["peak"]) < 1e-12
+    assert d["roofline"]["bound"] == "hbm" and d["roofline"]["actual_bound"] == "fp64_valu_issue"
+    # (64 columns are not the workload the committed counters were collected on: traffic stays null, never borrowed)
+    assert d["roofline"]["traffic"] is None and d["roofline"]["hbm_traffic_frac"] is None
     assert d["cpu_baseline"]["kind"] == "port" and d["cpu_baseline"]["cores"] >= 1 and d["value"] > 0
 
 

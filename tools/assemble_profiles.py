@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Turns the rocprofv3 CSVs of one profiling session (tools/profile_session.sh TAG WORKLOAD: gpurun_out/p<TAG>{a,b,f,
-w,g,f4}, kt<TAG>, bench_<TAG>.json) into the committed summaries profiles/r02_<workload>_{pmc.json,
+w,g,f4}, kt<TAG>, bench_<TAG>.json) into the committed summaries profiles/<ROUND>_<workload>_{pmc.json,
 kernel_stats.csv,bench.json}.  usage: assemble_profiles.py TAG [lbl|repwvl100] [ROUND]"""
 import collections
 import csv
@@ -16,7 +16,7 @@ import bench  # noqa: E402  (kernel_source_id, the byte constants)
 
 tag = sys.argv[1]
 wl = sys.argv[2] if len(sys.argv) > 2 else "lbl"
-rnd = sys.argv[3] if len(sys.argv) > 3 else "r02"
+rnd = sys.argv[3] if len(sys.argv) > 3 else "r03"
 b = json.load(open(f"gpurun_out/bench_{tag}.json"))
 KERNEL = b["roofline"]["kernel"]
 PM_STEPS = KT_STEPS = 1
