@@ -923,6 +923,26 @@ int rcm_dbg_stamps(rcm_ensemble *h, unsigned long long *out, int n) {
 #endif
 
 #ifdef RCM_WITH_VARIANTS  // test-side build only; not declared in include/rcm.h
+// Point-by-point evaluation of an elementary device function (k_eval_device_fn, rcm_variants.hpp); host arrays.
+int rcm_dbg_eval(int fn, int n, const double *a, const double *b, const double *c, double *out) {
+  if (n < 1 || !a || !b || !c || !out || fn < 0 || fn > 5) return fail(RCM_ERR_ARG, "rcm_dbg_eval: bad argument");
+  double *d = nullptr;
+  const size_t bytes = (size_t)n * sizeof(double);
+  HIPCK(hipMalloc((void **)&d, 4 * bytes));
+  hipError_t e = hipMemcpy(d, a, bytes, hipMemcpyHostToDevice);
+  if (e == hipSuccess) e = hipMemcpy(d + n, b, bytes, hipMemcpyHostToDevice);
+  if (e == hipSuccess) e = hipMemcpy(d + 2 * (size_t)n, c, bytes, hipMemcpyHostToDevice);
+  if (e == hipSuccess) {
+    hipLaunchKernelGGL(rcm::k_eval_device_fn, dim3((n + 255) / 256), dim3(256), 0, nullptr, fn, n, d, d + n,
+                       d + 2 * (size_t)n, d + 3 * (size_t)n);
+    e = hipGetLastError();
+  }
+  if (e == hipSuccess) e = hipMemcpy(out, d + 3 * (size_t)n, bytes, hipMemcpyDeviceToHost);
+  (void)hipFree(d);
+  if (e != hipSuccess) return fail(RCM_ERR_HIP, std::string("rcm_dbg_eval: ") + hipGetErrorString(e));
+  return RCM_OK;
+}
+
 int rcm_set_step_fusion(rcm_ensemble *h, int mode) {
   if (!h || mode < -1 || mode > 1) return fail(RCM_ERR_ARG, "rcm_set_step_fusion: mode must be -1 (automatic), 0 or 1");
   h->fusion = mode;

@@ -424,3 +424,30 @@ __global__ __launch_bounds__(64, RCM_PAIR_LB) void k_step_repwvl(Dev d, int firs
   }
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// The elementary device functions of the production kernels, evaluated point by point for the accuracy pins of
+// tests/test_gpu_parity.py: a different v_rcp_f64 precision or a regenerated coefficient table must
+// fail THERE, loudly, instead of moving flux parity by a few 1e-11.  Same sources, same compile-time defaults
+// (RCM_EXP_DEG, RCM_EXP_HALF, RCM_EXPPOS_HALF, RCM_RCP_NEWTON) as the product.
+//   fn 0  exp_trans(a, b)                  a = tau (clamped by the caller's range), b = a1 = -s*log2(e)
+//   fn 1  planck_mono_fast(a, b, c, 1/c)   a = xc, b = sc, c = T
+//   fn 2  cplkavg_fast_mid(a, b, c)        a = xm, b = hh, c = pc
+//   fn 3  exp_pos(a)
+//   fn 4  rcp_newton(a)
+//   fn 5  clamp_tau(a)
+// ---------------------------------------------------------------------------------------------
+__global__ void k_eval_device_fn(int fn, int n, const double *a, const double *b, const double *c, double *out) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  double r;
+  switch (fn) {
+    case 0: r = exp_trans(a[i], b[i]); break;
+    case 1: r = planck_mono_fast(a[i], b[i], c[i], 1.0 / c[i]); break;
+    case 2: r = cplkavg_fast_mid(a[i], b[i], c[i]); break;
+    case 3: r = exp_pos(a[i]); break;
+    case 4: r = rcp_newton(a[i]); break;
+    default: r = clamp_tau(a[i]); break;
+  }
+  out[i] = r;
+}

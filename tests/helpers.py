@@ -51,7 +51,8 @@ def set_step_fusion(e, mode):
     library has neither the kernel nor the entry point: asking it for mode 1 is an error, 0 / -1 a no-op."""
     if not hasattr(e._L, "rcm_set_step_fusion"):
         if mode == 1:
-            raise RuntimeError("the fused repwvl step kernel exists in the test-side build only")
+            from our_first_climate_model_amd import RcmError
+            raise RcmError(-1, "the fused repwvl step kernel exists in the test-side build only")
         return
     import ctypes as C
     e._L.rcm_set_step_fusion.argtypes = [C.c_void_p, C.c_int]

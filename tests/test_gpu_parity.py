@@ -4,6 +4,7 @@ Tolerances (BASELINE.json north_star / SURVEY.md 8d): fluxes <= 1e-6 W/m^2 absol
 <= 1e-12 relative, temperatures <= 1e-6 K after the stated number of steps.  fp64 with a different
 summation order and a different exp() implementation lands around 1e-10; the asserts use a margin
 tighter than the contract so a regression shows early."""
+import ctypes as C
 import os
 
 import numpy as np
@@ -673,3 +674,110 @@ def test_kernel_distance_from_a_long_double_evaluation_of_the_sweep(pkg, olib):
     import accuracy_vs_longdouble as acc
     for eg, eo, ego in acc.run(3000, lambda *_: None):
         assert eg <= 5e-11 and eo <= 5e-11 and ego <= 2e-9, (eg, eo, ego)
+
+
+# ---- accuracy budget of the elementary device functions -------------------------
+def _dev_eval(variants, fn, a, b=None, c=None):
+    """rcm_dbg_eval of the TEST-SIDE build (same device sources and compile-time defaults as the product)."""
+    a = np.ascontiguousarray(a, dtype=np.float64)
+    b = np.zeros_like(a) if b is None else np.ascontiguousarray(b, dtype=np.float64)
+    c = np.ones_like(a) if c is None else np.ascontiguousarray(c, dtype=np.float64)
+    out = np.zeros_like(a)
+    dp = C.POINTER(C.c_double)
+    variants.rcm_dbg_eval.argtypes = [C.c_int, C.c_int, dp, dp, dp, dp]
+    rc = variants.rcm_dbg_eval(fn, a.size, a.ctypes.data_as(dp), b.ctypes.data_as(dp), c.ctypes.data_as(dp),
+                               out.ctypes.data_as(dp))
+    assert rc == 0, variants.rcm_last_error().decode()
+    return out
+
+
+def test_accuracy_budget_of_exp_and_reciprocal(variants):
+    """exp_trans (transmissions: degree-7 polynomial for 2^(f/2), squared), exp_pos (Planck arguments: degree 8,
+    squared) and rcp_newton (v_rcp_f64 + ONE Newton step) against long-double references.  The budget the flux
+    parity rests on, stated here so that a coefficient regeneration or another v_rcp_f64 precision fails loudly:
+      exp_trans <= 1.0e-12 relative wherever t >= 1e-300 (measured 7.4e-13), exact 1 at tau = 0, 0 past underflow;
+      exp_pos   <= 2.0e-14 relative on (0, 700)            (measured 7.1e-15);
+      rcp_newton <= 4.0e-15 relative                        (measured 2.1e-15: one Newton step squares the error of
+                                                             v_rcp_f64, which is therefore good to ~4.5e-8 = 2^-24.4
+                                                             on gfx950, not the 2^-26 assumed in round 2; a 2^-20
+                                                             v_rcp would give 1e-12 and fail here)."""
+    rng = np.random.default_rng(17)
+    ld = np.longdouble
+    log2e = 1.4426950408889634
+    # transmissions: tau in [1e-8, 3e4] x every angle of the 30-angle grid (and coarser/finer grids), tau*s up to 700+
+    tau = np.concatenate([10 ** rng.uniform(-8, 4.5, 150000), rng.uniform(0, 12, 50000), [0.0, 1e-300, 1e7]])
+    s = 1.0 / ((rng.integers(0, 64, tau.size) + 0.5) / rng.choice([30.0, 64.0, 8.0], tau.size))
+    a1 = -s * log2e                                    # (the host forms a1 the same way: rcm_create's schedule)
+    got = _dev_eval(variants, 0, tau, a1)
+    want = np.exp(ld(tau) * ld(a1) * np.log(ld(2.0)))  # what the kernel is asked for: 2^(tau*a1)
+    big = want >= 1e-300
+    rel = np.abs((ld(got[big]) - want[big]) / want[big]).astype(np.float64)
+    assert rel.max() <= 1.0e-12, rel.max()
+    assert got[tau == 0.0][0] == 1.0 and np.all(got[~big] <= 1e-299) and np.all(got >= 0.0) and np.all(got <= 1.0)
+    assert got[tau == 1e7][0] == 0.0
+    # Planck arguments
+    x = np.concatenate([10 ** rng.uniform(-3, np.log10(700.0), 150000), rng.uniform(0.0, 60.0, 50000)])
+    got = _dev_eval(variants, 3, x)
+    want = np.exp(ld(x))
+    rel = np.abs((ld(got) - want) / want).astype(np.float64)
+    assert rel.max() <= 2.0e-14, rel.max()
+    d = np.concatenate([10 ** rng.uniform(-3, 300, 100000), -10 ** rng.uniform(-3, 3, 1000)])
+    got = _dev_eval(variants, 4, d)
+    rel = np.abs(ld(got) * ld(d) - 1).astype(np.float64)
+    assert rel.max() <= 4.0e-15, rel.max()
+    # the clamp keeps NaN a NaN and the range [-10, 1e7]
+    v = np.array([np.nan, -11.0, -10.0, 0.0, 5.0, 1e7, 2e7, np.inf, -np.inf])
+    got = _dev_eval(variants, 5, v)
+    assert np.isnan(got[0]) and got[1:].tolist() == [-10.0, -10.0, 0.0, 5.0, 1e7, 1e7, 1e7, -10.0]
+
+
+def test_accuracy_budget_of_the_planck_functions(variants, olib):
+    """planck_mono_fast (repwvl) against the oracle's monochromatic Planck (= the reference's compiled cplkavg
+    overloads, bit for bit: tests/test_reference_pins.py) over x = hc/(lambda k T) in (1e-3, 700): <= 1e-13 relative
+    (measured 4.4e-14 on 0.01 <= x <= 50, 3.9e-13 at the cancelling small-x end).  cplkavg_fast_mid (lbl: midpoint
+    + curvature, one exp, one reciprocal) against the oracle's cplkavg (= compiled cplkavg.cpp bit for bit) on narrow
+    bands, hh < 2e-3: <= 1e-13 relative where the reference's Simpson iteration has converged to rounding, i.e. over
+    the thermal range x in (0.05, 60) (measured 4e-15; outside it the REFERENCE's own 1e-6 convergence test governs)."""
+    rng = np.random.default_rng(23)
+    hP, cL, kB = 6.62607e-34, 299792458.0, 1.380649e-23
+    n = 20000
+    T = rng.uniform(150.0, 340.0, n)
+    x = 10 ** rng.uniform(-3, np.log10(700.0), n)
+    lam_nm = hP * cL / (x * kB * T) * 1e9
+    wgt = rng.normal(size=n) * 10 ** rng.uniform(0, 5, n)
+    # the per-wavelength constants exactly as rcm_set_repwvl_tables forms them (main.cpp:188-191 order)
+    lam = lam_nm * 1e-9
+    pnum = wgt * 2 * hP * cL ** 2
+    lam5 = lam ** 5
+    xc = (6.62607e-34 * 299792458.0) / (lam * kB)
+    sc = pnum / lam5 / 1e9
+    got = _dev_eval(variants, 1, xc, sc, T)
+    want = np.array([olib.orc_planck_mono(float(l), float(w), float(t)) for l, w, t in zip(lam_nm, wgt, T)])
+    ok = np.isfinite(want) & (np.abs(want) > 1e-290)
+    rel = np.where(ok, np.abs((got - want) / np.where(ok, want, 1.0)), 0.0)
+    # the rounding of the ARGUMENT x (1.1e-16 relative in either implementation) is amplified x-fold by exp, and
+    # exp(x) - 1 cancels below x ~ 0.01: the budget is stated on the thermal range (repwvl: 0.3 < x < 24) and, with
+    # those two effects allowed for, on the whole range
+    thermal = ok & (x >= 0.01) & (x <= 50.0)
+    worst_thermal, worst_all = rel[thermal].max(), rel.max()
+    print(f"planck_mono_fast: max rel err {worst_thermal:.2e} on 0.01 <= x <= 50, {worst_all:.2e} on (1e-3, 700)")
+    assert ok.sum() > 0.95 * n and thermal.sum() > 0.5 * n
+    assert worst_thermal <= 1e-13, worst_thermal
+    assert np.all(rel <= 2e-14 + 1.5e-15 * x + 1e-15 / x), worst_all   # measured: 3.9e-13 at the small-x end
+    # band Planck on narrow bands
+    C2, sigdpi = 1.438786, 5.67032e-8 / np.pi
+    m = 6000
+    T = rng.uniform(150.0, 340.0, m)
+    xm = 10 ** rng.uniform(np.log10(0.05), np.log10(60.0), m)
+    wn_mid = xm * T / C2                                   # wavenumber [1/cm] of the band centre
+    relw = 10 ** rng.uniform(-6.5, -3.2, m)                # relative band width: hh = xm*relw < 2e-3
+    wlo, whi = wn_mid * (1 - relw / 2), wn_mid * (1 + relw / 2)
+    lam_lo, lam_hi = 1e7 / whi, 1e7 / wlo                  # nm, increasing
+    v0, v1 = C2 * (1e7 / lam_hi) / T, C2 * (1e7 / lam_lo) / T
+    keep = (v1 - v0) < 2e-3
+    pc = sigdpi * T ** 4 * 0.15398973382026507             # sigdpi * t^4 * 15/pi^4 (cplkavg.cpp:135, :240)
+    got = _dev_eval(variants, 2, 0.5 * (v0 + v1), v1 - v0, pc)
+    want = np.array([olib.orc_cplkavg(float(a), float(b), float(t)) for a, b, t in zip(lam_lo, lam_hi, T)])
+    rel = np.abs((got[keep] - want[keep]) / want[keep])
+    print(f"cplkavg_fast_mid: max rel err {rel.max():.2e} over {int(keep.sum())} narrow bands")
+    assert keep.sum() > 0.9 * m and rel.max() <= 1e-13, (rel.max(), int(np.argmax(rel)))
