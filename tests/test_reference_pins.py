@@ -298,3 +298,51 @@ def test_lower_pos_bit_identical(olib, golden):
             assert L.ref_lower_pos(_p(g), g.size, float(x)) == olib.orc_lower_pos(_p(g), g.size, float(x)), (g, x)
             n += 1
     assert n > 4000
+
+
+def test_read_tau_against_an_independent_array_statement(olib, golden):
+    """a5's interpolation arithmetic cannot be pinned by a compiled reference (module docstring).  Second opinion, so
+    that the one unpinned row does not rest on a single restatement: the same rules written again, array-wise and
+    from the text of repwvl_thermal.cpp:197-248 (not from oracle/rcm_oracle.c) -- brackets by a vectorised sign-change
+    search, the four corners gathered with fancy indexing, the corner-difference form, species sum, number density --
+    against orc_read_tau on test.atm x Reduced10/20/100 and on perturbed profiles that leave the table on both sides.
+    Corroboration, not a pin.  Agreement to 1e-14 relative (numpy sums the nine species in the same order; the
+    only freedom is FMA-free rounding, identical here), in practice bit for bit."""
+    atm, _ = ol.atm_load(olib, os.path.join(golden, "test.atm"))
+    ci = ol.column_init(olib, atm, 1.0, 1.0)
+    rng = np.random.default_rng(8)
+
+    def lower_pos(grid, x):                     # :19-45, vectorised over x; grid 1-D
+        d = np.sign(grid[None, :] - x[:, None]).astype(int)
+        change = d[:, 1:] != d[:, :-1]          # first p >= 1 whose sign differs from its predecessor's
+        first = np.where(change.any(axis=1), change.argmax(axis=1), grid.size - 2)
+        return np.minimum(first, grid.size - 2)
+
+    for table in ("Reduced10", "Reduced20", "Reduced100"):
+        t = ol.read_rtab(os.path.join(golden, f"{table}Forcing.rtab"))
+        for case in range(4):
+            T = ci["Tlayer"] + (0.0 if case == 0 else rng.normal(size=20) * (5.0, 40.0, 150.0)[case - 1])
+            vmr = ci["vmr9"] * (1.0 if case == 0 else rng.uniform(0.3, 3.0, (9, 1)))
+            want = _orc_tau(olib, t, ci, T, vmr, cloud=False)
+            pPa = ci["plevel"][::-1] * 100.0                     # :68-73, :89: surface first
+            Tr, vr = T[::-1], vmr[:, ::-1]
+            midP = (pPa[1:] + pPa[:-1]) / 2                      # :214
+            nd = (pPa[:-1] - pPa[1:]) * 6.02214076e23 / 0.0289647 / 9.80665   # :202
+            ip = lower_pos(t["p_grid"], midP)                    # :226
+            tgrid = t["t_ref"][ip][:, None] + t["t_pert"][None, :]             # :229-231, [layer][pert]
+            it = np.array([lower_pos(tgrid[l], Tr[l:l + 1])[0] for l in range(20)])   # :232
+            L = np.arange(20)
+            delT = (Tr - tgrid[L, it]) / (tgrid[L, it + 1] - tgrid[L, it])     # :239
+            delP = (midP - t["p_grid"][ip]) / (t["p_grid"][ip + 1] - t["p_grid"][ip])   # :240
+            x = t["xsec"]                                        # [pert][species][wvl][p]
+            tau = np.zeros((t["n_wvl"], 20))
+            for s in range(9):                                   # :212, species order of :102-110
+                c0 = np.stack([x[it[l], s, :, ip[l]] for l in range(20)], axis=1)      # [wvl][layer], :235
+                cT = np.stack([x[it[l] + 1, s, :, ip[l]] for l in range(20)], axis=1) - c0
+                cP = np.stack([x[it[l], s, :, ip[l] + 1] for l in range(20)], axis=1) - c0
+                cPT = np.stack([x[it[l] + 1, s, :, ip[l] + 1] for l in range(20)], axis=1) - cP - cT - c0
+                xs = c0 + cT * delT[None, :] + cP * delP[None, :] + cPT * delT[None, :] * delP[None, :]   # :241
+                tau += xs * vr[s][None, :]                       # :244
+            tau *= nd[None, :]                                   # :246
+            tau = tau[:, ::-1]                                   # stored top first (:244 index)
+            np.testing.assert_allclose(tau, want, rtol=1e-14, atol=0, err_msg=f"{table} case {case}")
