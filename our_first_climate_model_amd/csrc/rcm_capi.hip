@@ -464,8 +464,8 @@ int launch_step(rcm_ensemble *h, bool have_pre, bool next_pre) {
   }
   int post_waves = dp.nchunk / 16;  // waves per column in k_post: one per 16 chunk partials, 1..16
   post_waves = post_waves < 1 ? 1 : (post_waves > 16 ? 16 : post_waves);
-  if (dp.nchunk <= 16)  // few records per column: a wave per column, four columns per block
-    hipLaunchKernelGGL(rcm::k_post_wave, dim3((h->ncol + rcm::WPB - 1) / rcm::WPB), dim3(64 * rcm::WPB), 0, h->stream, dp,
+  if (dp.nchunk <= 16)  // few records per column: half a wave per column, eight columns per block
+    hipLaunchKernelGGL(rcm::k_post_wave, dim3((h->ncol + rcm::kPostCols - 1) / rcm::kPostCols), dim3(64 * rcm::WPB), 0, h->stream, dp,
                        next_pre ? 1 : 0);
   else
     hipLaunchKernelGGL(rcm::k_post, dim3(h->ncol), dim3(64 * post_waves), 0, h->stream, dp, next_pre ? 1 : 0);

