@@ -261,6 +261,7 @@ constexpr int kPostSlices = 32;  // blocks per column of the first-stage chunk s
 
 bool use_flat(const rcm_ensemble *h) {
   return h->mode == rcm::MODE_REPWVL && h->flat && h->pair && h->exp_variant == 1 && h->user_chunks == 0 &&
+         (long long)h->ncol * h->d.n_wvl < (1ll << 31) - 4096 &&  // 32-bit item arithmetic in the kernel
          h->d.n_wvl >= 8;  // at most 127/8 + 2 = 17 column images per block: 17 x 3 792 B + 22.5 KB staging = 87 KB of LDS
                            // (one block per CU; n_wvl >= 22 -> 7 images, 49 KB: three blocks per CU; 100 -> 3 images, 34 KB)
 }

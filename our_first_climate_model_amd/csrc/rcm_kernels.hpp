@@ -1102,14 +1102,21 @@ __global__ __launch_bounds__(64 * FWPB, RCM_FLAT_LB) void k_rt_repwvl_flat(Dev d
   double(*st)[64] = reinterpret_cast<double(*)[64]>(s_dyn + (size_t)maxc * sizeof(RepwvlPairLds) +
                                                     (size_t)wib * (NH + 1) * 64 * sizeof(double));
   const int p = PairRw::parity(lane);
-  const long nw = d.n_wvl;
-  const long nflat = (long)d.ncol * nw;
-  const long blk0 = (long)blockIdx.x * (FWPB * 32);
-  const long flat0 = blk0 + wib * 32;
-  int cb_first = 0, ncb = 0;  // first column and number of columns the block touches
+  // 32-bit item arithmetic: ncol * n_wvl < 2^31 - 2^12 is a condition of this kernel (use_flat, rcm_capi.hip).  The
+  // 64-bit forms cost four scalar divisions of ~130 instructions per wave and ONE PER LANE (130 of a wave's 4 490
+  // VALU instructions); here: one 32-bit scalar division per wave, everything else from remainders < n_wvl + 128
+  // by compare-and-count (n_wvl >= 8: a block spans at most 17 columns, a wave at most 5).
+  const int nw = d.n_wvl;
+  const int nflat = d.ncol * nw;
+  const int blk0 = (int)blockIdx.x * (FWPB * 32);
+  const int flat0 = blk0 + wib * 32;
+  int cb_first = 0, ncb = 0, cb_rem = 0;  // first column the block touches, how many, and blk0's offset in the first
   if (blk0 < nflat) {
-    cb_first = (int)(blk0 / nw);
-    ncb = (int)(min(blk0 + FWPB * 32 - 1, nflat - 1) / nw) - cb_first + 1;
+    cb_first = (int)((unsigned)blk0 / (unsigned)nw);
+    cb_rem = blk0 - cb_first * nw;
+    const int last_rem = cb_rem + min(FWPB * 32 - 1, nflat - 1 - blk0);  // offset of the block's last item from the
+    ncb = 1;                                                             // start of column cb_first: < n_wvl + 128
+    for (int t = nw; t <= last_rem; t += nw) ++ncb;                      // (wave-uniform: scalar, <= 16 rounds)
   }
   RCM_PT_STAMP(16);
 #ifdef RCM_DBG_NOIMAGE  // ablation builds only: all-zero images (valid offsets, no work)
@@ -1126,11 +1133,15 @@ __global__ __launch_bounds__(64 * FWPB, RCM_FLAT_LB) void k_rt_repwvl_flat(Dev d
   for (int j = 0; j <= NH; ++j) acc1[j] = 0.0;
 #pragma unroll
   for (int j = 0; j < NH; ++j) acc2[j] = 0.0;
-  const long flat = flat0 + PairRw::index(lane);
-  int col = -1;
+  const int flat = flat0 + PairRw::index(lane);
+  // the lane's column and wavelength: offset from the start of column cb_first, minus whole columns (<= 16 of them)
+  int col = -1, w = cb_rem + (flat - blk0), dc = 0;
+#pragma unroll 1
+  for (int t = nw; t <= w && dc < 16; t += nw) ++dc;  // dc = w / nw, w < n_wvl + 128, n_wvl >= 8
+  w -= dc * nw;
   if (flat < nflat) {
-    col = (int)(flat / nw);
-    repwvl_pair_point<CUBE, NACT>(d, imgs[col - cb_first], p, (int)(flat - (long)col * nw), lane, st, acc1, acc2);
+    col = cb_first + dc;
+    repwvl_pair_point<CUBE, NACT>(d, imgs[dc], p, w, lane, st, acc1, acc2);
   }
   if (flat0 >= nflat) return;  // (whole wave)
 
@@ -1141,7 +1152,15 @@ __global__ __launch_bounds__(64 * FWPB, RCM_FLAT_LB) void k_rt_repwvl_flat(Dev d
   if (acc1[3] == 1.2345) d.partial[0] = acc2[1];
   return;
 #endif
-  const int c_first = (int)(flat0 / nw), c_last = (int)(min(flat0 + 31, nflat - 1) / nw);
+  // columns of the wave's 32 items: those of its first and of its last live lane-pair
+  int c_first = cb_first, c_last = cb_first;
+  {
+    const int r0 = cb_rem + wib * 32, r1 = cb_rem + min(flat0 + 31, nflat - 1) - blk0;
+    for (int t = nw; t <= r1; t += nw) {
+      c_first += t <= r0;
+      ++c_last;
+    }
+  }
   // Per column of the wave's 32 items: the 21 sums of either parity, in a fixed order.  Three DPP levels sum inside
   // the half-rows of 8 lanes (Pair<2>: a half-row is one parity); the four half-row sums of a parity meet in the
   // staging rows, where lane e (0..41) adds the four that make up record element e and stores it: ONE store
@@ -1162,8 +1181,8 @@ __global__ __launch_bounds__(64 * FWPB, RCM_FLAT_LB) void k_rt_repwvl_flat(Dev d
   }
   for (int c = c_first; c <= c_last; ++c) {
     const bool mine = col == c;
-    const long seg0 = max((long)c * nw, flat0);
-    const long slot = (seg0 - (long)c * nw + 31) / 32;
+    const int seg0 = max(c * nw, flat0);
+    const int slot = (seg0 - c * nw + 31) >> 5;
     double *out = d.partial + ((size_t)c * d.nchunk + slot) * PSTRIDE;  // E_down[21], E_up[21]
 #pragma unroll
     for (int v = 0; v < NLEV; ++v) {
