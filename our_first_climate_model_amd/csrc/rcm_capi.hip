@@ -262,8 +262,9 @@ constexpr int kPostSlices = 32;  // blocks per column of the first-stage chunk s
 bool use_flat(const rcm_ensemble *h) {
   return h->mode == rcm::MODE_REPWVL && h->flat && h->pair && h->exp_variant == 1 && h->user_chunks == 0 &&
          (long long)h->ncol * h->d.n_wvl < (1ll << 31) - 4096 &&  // 32-bit item arithmetic in the kernel
-         h->d.n_wvl >= 8;  // at most 127/8 + 2 = 17 column images per block: 17 x 3 792 B + 22.5 KB staging = 87 KB of LDS
-                           // (one block per CU; n_wvl >= 22 -> 7 images, 49 KB: three blocks per CU; 100 -> 3 images, 34 KB)
+         h->d.n_wvl >= 8;  // at most 127/8 + 2 = 17 column images per block, each the prefix the launch reads (1 552 B
+                           // for the 3 visited species of a CO2 sweep, 3 472 B for all 9) + 22.5 KB staging: 48 KB / 80 KB of
+                           // LDS at n_wvl = 8; Reduced10: 14 images, 44 KB (3 blocks per CU); Reduced100: 3 images, 27 KB
 }
 
 #ifdef RCM_WITH_VARIANTS
@@ -325,10 +326,12 @@ void launch_rt_pair(rcm_ensemble *h, int blocks) {
     hipLaunchKernelGGL((rcm::k_rt_lbl_pair<CUBE>), dim3(blocks), dim3(64 * rcm::WPB), 0, h->stream, h->d);
   } else if (use_flat(h)) {
     const int maxc = (rcm::FWPB * 32 - 1) / h->d.n_wvl + 2;  // columns the consecutive items of a block can touch
-    const size_t lds = (size_t)maxc * sizeof(rcm::RepwvlPairLds) + (size_t)rcm::FWPB * (rcm::NH + 1) * 64 * sizeof(double);
     const long waves = ((long)h->ncol * h->d.n_wvl + 31) / 32;
     // the instantiation that visits the fewest species >= the active ones (the entries past Dev::nact add +0)
     const int na = h->d.nact;
+    const int nvisit = na <= 2 ? 2 : na <= 3 ? 3 : na <= 4 ? 4 : na <= 5 ? 5 : na <= 7 ? 7 : 9;
+    const size_t lds = (size_t)maxc * rcm::repwvl_image_prefix_bytes(nvisit) +  // the images' prefixes (header + visited slots)
+                       (size_t)rcm::FWPB * (rcm::NH + 1) * 64 * sizeof(double);
     const auto kern = na <= 2 ? rcm::k_rt_repwvl_flat<CUBE, 2> : na <= 3 ? rcm::k_rt_repwvl_flat<CUBE, 3>
                     : na <= 4 ? rcm::k_rt_repwvl_flat<CUBE, 4> : na <= 5 ? rcm::k_rt_repwvl_flat<CUBE, 5>
                     : na <= 7 ? rcm::k_rt_repwvl_flat<CUBE, 7> : rcm::k_rt_repwvl_flat<CUBE, 9>;

@@ -1098,8 +1098,11 @@ __global__ __launch_bounds__(64 * FWPB, RCM_FLAT_LB) void k_rt_repwvl_flat(Dev d
   int lane = threadIdx.x & 63;
   RCM_PRIO_START(lane);
   const int wib = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  RepwvlPairLds *imgs = reinterpret_cast<RepwvlPairLds *>(s_dyn);  // the block's columns
-  double(*st)[64] = reinterpret_cast<double(*)[64]>(s_dyn + (size_t)maxc * sizeof(RepwvlPairLds) +
+  // the block's columns: image sl at s_dyn + sl * kImg -- only the prefix this instantiation reads is kept in LDS
+  // (1 552 of 3 792 B for NACT = 3: a 10-wavelength table's 14 images per block take 22 KB, not 53)
+  constexpr int kImg = repwvl_image_prefix_bytes(NACT);
+  auto img_at = [&](int sl) -> RepwvlPairLds & { return *reinterpret_cast<RepwvlPairLds *>(s_dyn + (size_t)sl * kImg); };
+  double(*st)[64] = reinterpret_cast<double(*)[64]>(s_dyn + (size_t)maxc * kImg +
                                                     (size_t)wib * (NH + 1) * 64 * sizeof(double));
   const int p = PairRw::parity(lane);
   // 32-bit item arithmetic: ncol * n_wvl < 2^31 - 2^12 is a condition of this kernel (use_flat, rcm_capi.hip).  The
@@ -1120,10 +1123,10 @@ __global__ __launch_bounds__(64 * FWPB, RCM_FLAT_LB) void k_rt_repwvl_flat(Dev d
   }
   RCM_PT_STAMP(16);
 #ifdef RCM_DBG_NOIMAGE  // ablation builds only: all-zero images (valid offsets, no work)
-  for (int i = threadIdx.x; i < (int)((size_t)ncb * sizeof(RepwvlPairLds) / 8); i += blockDim.x)
-    reinterpret_cast<double *>(imgs)[i] = 0.0;
+  for (int i = threadIdx.x; i < (int)((size_t)ncb * kImg / 8); i += blockDim.x)
+    reinterpret_cast<double *>(s_dyn)[i] = 0.0;
 #else
-  for (int sl = wib; sl < ncb; sl += FWPB) repwvl_pair_image_copy<NACT>(d, cb_first + sl, lane, imgs[sl]);
+  for (int sl = wib; sl < ncb; sl += FWPB) repwvl_pair_image_copy<NACT>(d, cb_first + sl, lane, img_at(sl));
 #endif
   __syncthreads();
   RCM_PT_STAMP(17);
@@ -1141,7 +1144,7 @@ __global__ __launch_bounds__(64 * FWPB, RCM_FLAT_LB) void k_rt_repwvl_flat(Dev d
   w -= dc * nw;
   if (flat < nflat) {
     col = cb_first + dc;
-    repwvl_pair_point<CUBE, NACT>(d, imgs[dc], p, w, lane, st, acc1, acc2);
+    repwvl_pair_point<CUBE, NACT>(d, img_at(dc), p, w, lane, st, acc1, acc2);
   }
   if (flat0 >= nflat) return;  // (whole wave)
 

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """A/B of library builds on the repwvl workload (10 000 x Reduced100) in ONE process: the three-kernel path
 (flattened RT kernel) and the fused whole-step kernel at forced lane-pairs-per-column (builds with -DRCM_LPC_ENV).
-    usage (GPU box): python tools/ab_repwvl.py [ncol=10000] [steps=100] [rounds=3]"""
+    usage (GPU box): python tools/ab_repwvl.py [ncol=10000] [steps=100] [rounds=3] [table=Reduced100]"""
 import glob
 import os
 import sys
@@ -17,10 +17,11 @@ import our_first_climate_model_amd as pkg
 ncol = int(sys.argv[1]) if len(sys.argv) > 1 else 10000
 steps = int(sys.argv[2]) if len(sys.argv) > 2 else 100
 rounds = int(sys.argv[3]) if len(sys.argv) > 3 else 3
+table = sys.argv[4] if len(sys.argv) > 4 else "Reduced100"
 libs = {"product": pkg.lib()}
 for so in sorted(glob.glob(os.path.join(ROOT, "our_first_climate_model_amd", "variants", "librcm_hip_*.so"))):
     libs[os.path.basename(so)[len("librcm_hip_"):-3]] = pkg.load_library(so)
-inp = H.make_inputs(pkg, "repwvl", ncol, table="Reduced100")
+inp = H.make_inputs(pkg, "repwvl", ncol, table=table)
 # the fused kernel exists only in builds with -DRCM_WITH_VARIANTS (add -DRCM_LPC_ENV to force its lane pairs per column)
 cases = [("flat", 0, None)] + ([("fused16", 1, "16"), ("fused32", 1, "32")] if os.environ.get("AB_FUSED") else [])
 ens = {}
