@@ -342,7 +342,7 @@ def main():
         # gfx950 correction of MI355X_MICROARCH.md's HBM section); only valid for the workload they were collected on
         traffic, traffic_src = None, None
         try:
-            if pmc["hbm_traffic"]["algorithmic_bytes_per_launch"] == alg_bytes:
+            if fresh and pmc["hbm_traffic"]["algorithmic_bytes_per_launch"] == alg_bytes:  # this kernel build, this workload
                 traffic, traffic_src = pmc["hbm_traffic"]["traffic_bytes_per_launch"], pmc_src
         except (TypeError, KeyError):
             pass
