@@ -99,7 +99,11 @@ int rcm_set_lbl_tables(rcm_ensemble *h, int n_nodes, const double *wvl,
  *   gas       [ncol][ngas][nlayer]    repwvl: absolute mixing ratios, 9 species;
  *                                      lbl: multipliers of the 5 species tables (1 = as tabulated)
  *   rel_hum   [ncol][nlayer]          frozen relative humidity of main.cpp:467-468
- * Resets the step counter and `time` to 0. */
+ * Resets the step counter and `time` to 0.
+ * repwvl: species whose profile is the same in EVERY column handed to this handle are summed into one table row set
+ * (DESIGN.md 5).  Which species those are depends on the columns the handle gets: a rank's shard of an ensemble, or a
+ * one-column handle, may merge a different set than the whole ensemble would, so the same column integrated under
+ * another sharding agrees to rounding (optical depths <= 1e-12 relative), not bit for bit. */
 int rcm_set_columns(rcm_ensemble *h, const double *Tlayer0, const double *T_surface0,
                     const double *gas, const double *rel_hum);
 
@@ -146,9 +150,12 @@ int rcm_get_profile(rcm_ensemble *h, int col, double *Tlayer_adj, double *theta,
 int rcm_get_tau(rcm_ensemble *h, int col, double *tau);
 /* The same optical depths AS THE PRODUCTION KERNELS FORM THEM (diagnostic; parity of rows a5 / a9): rcm_get_tau
  * evaluates read_tau's corner-DIFFERENCE form (repwvl_thermal.cpp:235-241); the thermal-RT kernels interpolate
- * with numDens-folded corner WEIGHTS and clamp to [-10, 1e7].  This getter runs the very device
- * functions of those kernels (column image + per-point optical-depth stage) and returns what they feed to
- * the sweep, same layout and same timing rules as rcm_get_tau. */
+ * with numDens-folded corner WEIGHTS and clamp to [-10, 1e7].  This getter follows the path the next
+ * rcm_step launch would take: on the flattened repwvl kernel (n_wvl >= 8, no pinned chunk count) it copies the
+ * column image STORED in device memory by the stepping kernels (rebuilt by the same store function when no step has
+ * written it since the inputs last changed) and visits the species count of that launch; on the chunked repwvl
+ * kernel and on lbl it builds the image in place, as those kernels do.  Returns what they feed to the sweep, same
+ * layout and same timing rules as rcm_get_tau. */
 int rcm_get_tau_production(rcm_ensemble *h, int col, double *tau);
 /* Current gas block [ncol][ngas][nlayer] (H2O row follows the feedback). */
 int rcm_get_gas(rcm_ensemble *h, double *gas);
