@@ -737,7 +737,7 @@ def test_accuracy_budget_of_the_planck_functions(variants, olib):
     (measured 4.4e-14 on 0.01 <= x <= 50, 3.9e-13 at the cancelling small-x end).  cplkavg_fast_mid (lbl: midpoint
     + curvature, one exp, one reciprocal) against the oracle's cplkavg (= compiled cplkavg.cpp bit for bit) on narrow
     bands, hh < 2e-3: <= 1e-13 relative where the reference's Simpson iteration has converged to rounding, i.e. over
-    the thermal range x in (0.05, 60) (measured 4e-15; outside it the REFERENCE's own 1e-6 convergence test governs)."""
+    the thermal range x in (0.05, 60) (measured 2.4e-14; outside it the REFERENCE's own 1e-6 convergence test governs)."""
     rng = np.random.default_rng(23)
     hP, cL, kB = 6.62607e-34, 299792458.0, 1.380649e-23
     n = 20000
@@ -785,3 +785,114 @@ def test_accuracy_budget_of_the_planck_functions(variants, olib):
     rel = np.abs((got[keep] - want[keep]) / want[keep])
     print(f"cplkavg_fast_mid: max rel err {rel.max():.2e} over {int(keep.sum())} narrow bands")
     assert keep.sum() > 0.9 * m and rel.max() <= 1e-13, (rel.max(), int(np.argmax(rel)))
+
+
+# ---- the HIP path against the reference's OWN compiled code (oracle/_ref/libref_main.so travels with gpurun) -----
+@pytest.mark.parametrize("table", ["Reduced10", "Reduced100"])
+def test_gpu_against_the_compiled_reference_itself(pkg, olib, golden, table):
+    """Not through the oracle: the fluxes, time step and temperatures of the HIP path against main.cpp's own
+    radiative_transfer / calculate_timestep / thermodynamics / adjustment / feedback, compiled from where the file
+    lies (oracle/Makefile; tests/test_reference_pins.py has the oracle == that library bit for bit).  test.atm, the
+    reference's tables, 101 iterations of the loop body main.cpp:536-581 driven with the reference's functions; the
+    one thing the compiled reference cannot supply, read_tau's interpolation, comes (i) from the GPU itself at step 0
+    -- the sweep alone, same optical depths on both sides -- and (ii) from the oracle's restatement along the chain.
+    Contract: fluxes <= 1e-6 W/m2, temperatures <= 1e-6 K (asserted tighter)."""
+    import oracle_lib as ol
+    ref = ol.load_ref_main()
+    if ref is None:
+        pytest.skip("oracle/_ref/libref_main.so not built (reference tree absent at build time)")
+    _p = ol._p
+    inp = H.make_inputs(pkg, "repwvl", 1, table=table, perturb=False)
+    t, c = inp["table"], inp["cols"]
+    g = H.gpu_ensemble(pkg, inp)
+    sol = np.zeros(7)
+    ref.ref_solar(_p(sol))
+    assert inp["solar"] == sol[6]
+    atm, _ = ol.atm_load(olib, os.path.join(golden, "test.atm"))
+    ci = ol.column_init(olib, atm, 1.0, 1.0)
+    T, Ts, vmr = ci["Tlayer"].copy(), 288.2, ci["vmr9"].copy()
+    np.testing.assert_array_equal(T, c["Tlayer0"][0])
+    # (i) step 0, the sweep alone: the optical depths the production kernel really forms, handed to the reference
+    tau_gpu = g.get_tau_production(0)
+    theta = np.zeros(20)
+    T_adj = T.copy()
+    ref.ref_convective_adjustment(_p(T_adj), _p(theta), _p(ci["conv"]))
+    Ed, Eu, dE = ol.ref_radiative_transfer(ref, tau_gpu, t["wvl"], t["weight"], T_adj, Ts, sol[6])
+    g.step(1)
+    f, s = g.get_fluxes(), g.get_state()
+    assert H.max_abs(f["E_down"][0], Ed) <= FLUX_TIGHT and H.max_abs(f["E_up"][0], Eu) <= FLUX_TIGHT
+    assert H.max_abs(f["dE"][0], dE) <= FLUX_TIGHT
+    dt = ref.ref_calculate_timestep(50.0, _p(dE))
+    assert abs(s["timestep"][0] - dt) <= 1e-9 * dt
+    # (ii) the whole chain with the reference's functions, tau by the oracle's read_tau
+    def tau_of(Tl, v):
+        tau = np.zeros((t["n_wvl"], 20))
+        xs = np.ascontiguousarray(t["xsec"])
+        olib.orc_read_tau(t["n_tpert"], t["n_species"], t["n_wvl"], t["n_p"], _p(t["p_grid"]), _p(t["t_ref"]),
+                          _p(t["t_pert"]), _p(xs), 21, _p(ci["plevel"]), _p(np.ascontiguousarray(Tl)),
+                          _p(np.ascontiguousarray(v)), _p(tau))
+        ref.ref_cloud_into_tau(_p(tau), t["n_wvl"])
+        return tau
+    tau = tau_of(T, vmr)                                   # main.cpp:500-504: pre-adjustment profile
+    worst_T = 0.0
+    for i in range(101):
+        ref.ref_convective_adjustment(_p(T), _p(theta), _p(ci["conv"]))
+        if i != 0:
+            h2o = np.zeros(20)
+            ref.ref_water_vapor_feedback(_p(T), _p(ci["rel_hum"]), _p(ci["player"]), _p(h2o))
+            vmr[0] = h2o
+            tau = tau_of(T, vmr)
+        Ed, Eu, dE = ol.ref_radiative_transfer(ref, tau, t["wvl"], t["weight"], T, Ts, sol[6])
+        dt = ref.ref_calculate_timestep(50.0, _p(dE))
+        Ts = ref.ref_thermodynamics(_p(T), 50.0, _p(dE), dt, _p(ci["conv"]))
+        if i > 0:
+            g.step(1)
+        if i in (0, 1, 10, 50, 100):
+            s, f = g.get_state(), g.get_fluxes()
+            worst_T = max(worst_T, H.max_abs(s["Tlayer"][0], T), abs(s["T_surface"][0] - Ts))
+            assert H.max_abs(f["E_down"][0], Ed) <= 1e-7 and H.max_abs(f["E_up"][0], Eu) <= 1e-7, i
+            assert H.max_abs(f["dE"][0], dE) <= 1e-7, i
+    assert worst_T <= 1e-8, worst_T     # contract 1e-6 K; measured ~1e-11
+    assert 295.0 < Ts < 305.0
+
+
+def test_lbl_fluxes_against_the_reference_pieces_wired_together(pkg, olib):
+    """The lbl path has no reference driver (a9), but every PIECE of it is reference code that compiles here: the band
+    Planck source cplkavg.cpp (libref_cplkavg.so) and main.cpp's monochromatic_radiative_transfer + the dE formula
+    (libref_main.so).  Wired together by the documented composition (band b = wvl[b]..wvl[b+1], node b's
+    optical depth, weight 1) and fed the optical depths the GPU reports, they must give the GPU's fluxes: this checks
+    the production lbl kernel (narrow-band Planck, lane-pair sweep, chunked sums) against the reference's own
+    arithmetic, not against a restatement.  The reference's sweep forms the surface radiance itself, as
+    weight x monochromatic Planck (main.cpp:301): the weight handed to it is band / monochromatic at T_surface, so
+    that product is the band integral to one rounding."""
+    import ctypes
+    import oracle_lib as ol
+    ref = ol.load_ref_main()
+    p = os.path.join(H.ROOT, "oracle", "_ref", "libref_cplkavg.so")
+    if ref is None or not os.path.exists(p):
+        pytest.skip("oracle/_ref not built (reference tree absent at build time)")
+    band = getattr(ctypes.CDLL(p), "_Z7cplkavgddd")       # double cplkavg(double, double, double), cplkavg.h:7
+    band.restype, band.argtypes = ctypes.c_double, [ctypes.c_double] * 3
+    _p = ol._p
+    inp = H.make_inputs(pkg, "lbl", 3, n_nodes=700, atm="fpda.lbl.atm")
+    g = H.gpu_ensemble(pkg, inp)
+    wvl, c = inp["wvl"], inp["cols"]
+    mu, dmu = ol.ref_mu()
+    for col in (0, 2):
+        tau = g.get_tau_production(col)                    # [699][20], cloud included
+        T0, Ts = c["Tlayer0"][col].copy(), float(c["T_surface0"][col])
+        theta = np.zeros(20)
+        ref.ref_convective_adjustment(_p(T0), _p(theta), _p(c["conv"]))
+        Ed, Eu = np.zeros(21), np.zeros(21)                # radiative_transfer's fill (main.cpp:326-327)
+        for b in range(wvl.size - 1):                      # its loop over wavelengths (main.cpp:329-335)
+            B = np.array([band(wvl[b], wvl[b + 1], float(t)) for t in T0])
+            w_sfc = band(wvl[b], wvl[b + 1], Ts) / ref.ref_cplkavg_scalar(float(wvl[b]), 1.0, Ts)
+            ref.ref_monochromatic_radiative_transfer(_p(B), b, _p(np.ascontiguousarray(tau[b])), w_sfc, wvl.size - 1,
+                                                     _p(wvl), _p(mu), dmu, _p(T0), Ts, _p(Ed), _p(Eu))
+        dE = Ed[:-1] - Ed[1:] + Eu[1:] - Eu[:-1]           # main.cpp:337-339
+        dE[-1] += inp["solar"] + Ed[-1] - Eu[-1]           # main.cpp:341
+        if col == 0:
+            g.step(1)
+            f = g.get_fluxes()
+        assert H.max_abs(f["E_down"][col], Ed) <= FLUX_TIGHT and H.max_abs(f["E_up"][col], Eu) <= FLUX_TIGHT, col
+        assert H.max_abs(f["dE"][col], dE) <= FLUX_TIGHT, col

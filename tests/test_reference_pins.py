@@ -346,3 +346,41 @@ def test_read_tau_against_an_independent_array_statement(olib, golden):
             tau *= nd[None, :]                                   # :246
             tau = tau[:, ::-1]                                   # stored top first (:244 index)
             np.testing.assert_allclose(tau, want, rtol=1e-14, atol=0, err_msg=f"{table} case {case}")
+
+
+def test_oracle_lbl_sweep_against_the_reference_pieces_wired_together(ref, olib, rcm):
+    """a9 has no reference driver, but its pieces are reference code: cplkavg.cpp (band Planck) and main.cpp's
+    monochromatic_radiative_transfer + dE formula.  Wired together by the documented composition, on the
+    oracle's optical depths, they reproduce the oracle's lbl radiative transfer.  Not bit for bit, by construction:
+    the reference's sweep forms the surface radiance as weight x monochromatic Planck (main.cpp:301), so the band
+    integral at T_surface enters through a weight = band / monochromatic -- one extra rounding on one term.  Layers:
+    the reference's own cplkavg.cpp values, identical to the oracle's (test_oracle_pins.py)."""
+    import ctypes as C
+    import helpers as H
+    p = os.path.join(ol.REF_DIR, "libref_cplkavg.so")
+    if not os.path.exists(p):
+        pytest.skip("oracle/_ref/libref_cplkavg.so not built")
+    band = getattr(C.CDLL(p), "_Z7cplkavgddd")
+    band.restype, band.argtypes = C.c_double, [C.c_double] * 3
+    inp = H.make_inputs(rcm, "lbl", 2, n_nodes=300, atm="fpda.lbl.atm")
+    o = H.oracle_ensemble(olib, inp, threads=1)
+    wvl, c = inp["wvl"], inp["cols"]
+    mu, dmu = ol.ref_mu()
+    taus = [o.get_tau(k) for k in range(2)]
+    o.step(1)
+    f = o.get_fluxes()
+    for col in range(2):
+        T0, Ts = c["Tlayer0"][col].copy(), float(c["T_surface0"][col])
+        theta = np.zeros(20)
+        ref.ref_convective_adjustment(_p(T0), _p(theta), _p(c["conv"]))
+        Ed, Eu = np.zeros(21), np.zeros(21)
+        for b in range(wvl.size - 1):
+            B = np.array([band(wvl[b], wvl[b + 1], float(t)) for t in T0])
+            w_sfc = band(wvl[b], wvl[b + 1], Ts) / ref.ref_cplkavg_scalar(float(wvl[b]), 1.0, Ts)
+            ref.ref_monochromatic_radiative_transfer(_p(B), b, _p(np.ascontiguousarray(taus[col][b])), w_sfc,
+                                                     wvl.size - 1, _p(wvl), _p(mu), dmu, _p(T0), Ts, _p(Ed), _p(Eu))
+        dE = Ed[:-1] - Ed[1:] + Eu[1:] - Eu[:-1]
+        dE[-1] += inp["solar"] + Ed[-1] - Eu[-1]
+        assert f["E_down"][col].tolist() == Ed.tolist()          # no surface term in E_down: bit for bit
+        np.testing.assert_allclose(f["E_up"][col], Eu, rtol=0, atol=1e-12)
+        np.testing.assert_allclose(f["dE"][col], dE, rtol=0, atol=1e-12)
