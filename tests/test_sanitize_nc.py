@@ -4,6 +4,7 @@ feeds it the reference's tables and seeded byte mutations, splices and truncatio
 every case must return RCM_OK or RCM_ERR_FORMAT / RCM_ERR_IO with a message -- no sanitizer report, no other code.
 Host code only (the GPU box refuses device sanitizers); `make asan-nc` runs the same harness with more cases."""
 import os
+import re
 import subprocess
 
 import pytest
@@ -30,5 +31,7 @@ def test_nc_reader_mutation_fuzz_under_asan_ubsan(tmp_path):
     assert "ERROR: AddressSanitizer" not in r.stderr and "runtime error" not in r.stderr, r.stderr[-4000:]
     last = r.stdout.strip().splitlines()[-1]
     assert last.startswith("nc_fuzz: 4000 cases:") and last.endswith(" 0 unexpected"), last
-    loaded, refused = int(last.split()[4]), int(last.split()[6])
+    m = re.match(r"nc_fuzz: 4000 cases: (\d+) loaded, (\d+) RCM_ERR_FORMAT, (\d+) RCM_ERR_IO, 0 unexpected$", last)
+    assert m, last
+    loaded, refused = int(m.group(1)), int(m.group(2))
     assert loaded >= 500 and refused >= 500, last   # both outcomes are really exercised
