@@ -1,5 +1,12 @@
 """CPU: the oracle against every fixture the reference holds for this path, and the
-host-side C-ABI functions against the oracle.  No GPU needed."""
+host-side C-ABI functions against the oracle.  No GPU needed.
+
+What pins what: the reference's own data -- output.txt (t = 0 rows, solar banners) -- and its compiled stand-alone
+translation units cplkavg.cpp / ascii.cpp (oracle/_ref) are PINS.  The numbers of tests/golden/survey_probe.json (the
+`probe` fixture: step-0 fluxes, time steps, T_surface after 101 steps) were recorded by the survey stage from a build
+of the reference with a stand-in <netcdf> header: the tests that compare with them ("..._to_reference" in their names,
+kept for continuity) are CORROBORATION, not pins.  The pins for Planck, sweep, time step, adjustment and feedback are
+in tests/test_reference_pins.py (oracle == the reference's compiled main.cpp body, bit for bit)."""
 import ctypes as C
 import os
 import re
