@@ -706,8 +706,9 @@ int orc_step(orc_ensemble *h, int nsteps) {
         orc_convective_adjustment(T, theta, h->conv, nl);                  /* :536-540 */
         { /* equilibrium residual of the build (no reference counterpart): change of the adjusted profile */
           double r = 0.0, *prev = h->Tprev + (size_t)c * nl;
-          for (int l = 0; l < nl; ++l) {
-            if (fabs(T[l] - prev[l]) > r) r = fabs(T[l] - prev[l]);
+          for (int l = 0; l < nl; ++l) { /* a NaN layer makes the residual NaN (as k_pre / post_column do): a */
+            const double dl = fabs(T[l] - prev[l]); /* column gone NaN must never pass for converged */
+            if (dl > r || dl != dl) r = dl;
             prev[l] = T[l];
           }
           h->resid[c] = (i == 0) ? 1e300 : r;

@@ -92,7 +92,7 @@ def test_sweep_windows_concatenate_to_the_full_sweep(rcm):
     np.testing.assert_array_equal(s0.co2_factor, parts[1].co2_factor)
 
 
-def _rank_equilibrium(rank, world, port, ncol_total, q):
+def _rank_equilibrium(rank, world, port, ncol_total, q, nan_column=None, tol=0.5, max_steps=60):
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import torch.distributed as dist
@@ -106,10 +106,12 @@ def _rank_equilibrium(rank, world, port, ncol_total, q):
         atm_cols, _ = pkg.atm_load(os.path.join(ROOT, "tests", "golden", "test.atm"))
         spec = pkg.perturbation_sweep(hi - lo, perturb_rh=True, perturb_ts=True, first=lo, total=ncol_total)
         cols = pkg.build_columns(atm_cols, spec, "repwvl")
+        if nan_column is not None and lo <= nan_column < hi:
+            cols["T_surface0"][nan_column - lo] = float("nan")
         inp = dict(mode="repwvl", ncol=hi - lo, cols=cols, solar=pkg.default_solar()["solar_irr"],
                    table=ol.read_rtab(os.path.join(ROOT, "tests", "golden", "Reduced10Forcing.rtab")))
         e = H.oracle_ensemble(ol.load(), inp, threads=1)
-        done, worst = run_to_equilibrium(e, 0.5, 60, check_every=5, dist=dist)
+        done, worst = run_to_equilibrium(e, tol, max_steps, check_every=5, dist=dist)
         q.put((rank, done, worst, float(e.get_residual().max())))
         dist.barrier()
     finally:
@@ -139,6 +141,25 @@ def test_two_ranks_stop_on_the_global_residual(rcm, olib):
     assert [g[1] for g in got] == [done1, done1]
     assert got[0][2] == got[1][2] == worst1
     assert max(g[3] for g in got) == worst1  # the global value is the larger of the two local ones
+
+
+def test_a_nan_column_on_one_rank_keeps_every_rank_from_converging(rcm):
+    """The all-reduce(max) of the residual carries a NaN as a FLAG (max is not NaN-propagating in every backend): a
+    column gone NaN on rank 1 must hold rank 0 -- whose own columns pass any tolerance -- to the step cap as well."""
+    import math
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_rank_equilibrium, args=(r, 2, port, 6, q, 5, 1e9, 15)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = sorted(q.get(timeout=240) for _ in range(2))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert [g[1] for g in got] == [15, 15] and all(math.isnan(g[2]) for g in got)
+    assert math.isfinite(got[0][3]) and math.isnan(got[1][3])   # rank 0's own residuals are finite, rank 1 holds the NaN
 
 
 def test_bench_self_launch_reaches_every_rank_without_a_gpu():
