@@ -182,8 +182,15 @@ def valu_issue(pmc, src, fresh, kernel_substr, points_per_launch, rt_avg_s):
         if not fresh or kernel_substr not in pmc["kernel"]:
             return None
         ipp = pmc["derived"]["valu_instructions_per_point"]
-        return {"instructions_per_64_points": ipp * 64, "source": src, "kernel_source_id": pmc["kernel_source_id"],
-                "issue_frac_at_2.4GHz": ipp * points_per_launch * 4 / (N_SIMD * NOMINAL_CLOCK_HZ * rt_avg_s)}
+        out = {"instructions_per_64_points": ipp * 64, "source": src, "kernel_source_id": pmc["kernel_source_id"],
+               "issue_frac_at_2.4GHz": ipp * points_per_launch * 4 / (N_SIMD * NOMINAL_CLOCK_HZ * rt_avg_s)}
+        # fp64 FLOP/s of the kernel from the same counters (wave64 instructions x 64 lanes; FMA = 2) against the vector
+        # peak: 1024 SIMDs x 16 fp64 FMA lanes/clk x 2 x 2.4 GHz = 78.6 TFLOP/s (half of MI355X_MICROARCH.md's 157.3 FP32)
+        c, pts = pmc["counters"], pmc["hbm_traffic"]["algorithmic_bytes_per_launch"] / (BYTES_PER_BAND if "lbl" in kernel_substr else BYTES_PER_RWVL)
+        flop_per_point = (2 * c["SQ_INSTS_VALU_FMA_F64"] + c["SQ_INSTS_VALU_MUL_F64"] + c["SQ_INSTS_VALU_ADD_F64"]) * 64 / pts
+        out["achieved_tflops_fp64"] = flop_per_point * points_per_launch / rt_avg_s / 1e12
+        out["peak_tflops_fp64_vector"] = N_SIMD * 32 * NOMINAL_CLOCK_HZ / 1e12
+        return out
     except (TypeError, KeyError, ValueError):
         return None
 
