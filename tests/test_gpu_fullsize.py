@@ -381,11 +381,18 @@ def test_lbl_run_to_equilibrium_matches_oracle(pkg, olib):
 
 
 # ---- multi-GPU path with HIP compute ---------------------------------------------------------------
+def _free_port():
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        return sk.getsockname()[1]
+
+
 def _bench(args, nproc=None, timeout=900):
     cmd = [sys.executable]
     if nproc:
         cmd += ["-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={nproc}", "--master-addr", "127.0.0.1",
-                "--master-port", "29631"]
+                "--master-port", str(_free_port())]
     cmd += [os.path.join(H.ROOT, "bench.py")] + args
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout)
     assert r.returncode == 0, r.stderr[-3000:]
@@ -440,11 +447,11 @@ def test_nccl_leg_with_the_one_rank_this_box_allows(pkg, tmp_path):
     assert a.shape == (64, 21) and np.array_equal(a, b)
 
 
-def _equilibrium_example(args, nproc=None, port=29641, timeout=900):
+def _equilibrium_example(args, nproc=None, timeout=900):
     cmd = [sys.executable]
     if nproc:
         cmd += ["-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={nproc}", "--master-addr", "127.0.0.1",
-                "--master-port", str(port)]
+                "--master-port", str(_free_port())]
     cmd += [os.path.join(H.ROOT, "examples", "equilibrium_ensemble.py"), "--progress", "0"] + args
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout)
     assert r.returncode == 0, r.stderr[-3000:]
@@ -473,12 +480,12 @@ def test_equilibrium_stop_rule_across_two_ranks_with_hip_compute(pkg, tmp_path):
     assert np.all((a[:, 20] > 280.0) & (a[:, 20] < 320.0)) and np.ptp(a[:, 20]) > 0.1
     # column 12 lives on rank 1; rank 0's own columns all converge, the run must not
     d3 = _equilibrium_example(["--ncol", "16", "--nodes", "1025", "--tol", "1e9", "--check-every", "5", "--max-steps",
-                               "20", "--backend", "gloo", "--nan-column", "12", "--save-state", two], nproc=2, port=29643)
+                               "20", "--backend", "gloo", "--nan-column", "12", "--save-state", two], nproc=2)
     assert not d3["converged"] and d3["steps"] == 20 and d3["residual_K_per_step"] != d3["residual_K_per_step"]
     c = np.load(two)
     assert np.isnan(c[12]).all() and np.isfinite(np.delete(c, 12, axis=0)).all()
     d4 = _equilibrium_example(["--ncol", "16", "--nodes", "1025", "--tol", "1e9", "--check-every", "5", "--max-steps",
-                               "20", "--backend", "gloo"], nproc=2, port=29645)
+                               "20", "--backend", "gloo"], nproc=2)
     assert d4["converged"] and d4["steps"] == 5       # the same run without the NaN stops at the first check
 
 
