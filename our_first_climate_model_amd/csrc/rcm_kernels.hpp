@@ -1080,7 +1080,8 @@ __device__ __forceinline__ void post_column(const Dev &d, int c, int l, const Po
 //  * the per-column sums are masked (a lane contributes its sums to the column its item belongs to and zero to the
 //    others): three DPP levels inside the half-rows of 8 lanes, then the four half-row sums of a parity meet in the
 //    staging rows and one lane per output adds them -- not serial loops through LDS, no butterfly through ds_swizzle;
-//  * 34 KB of LDS per block (Reduced100: 3 images + 4 staging areas) and <= 128 VGPRs: 4 waves per SIMD.
+//  * 27 KB of LDS per block (Reduced100, CO2 sweep: 3 image prefixes of 1 552 B + 4 staging areas) and <= 128 VGPRs:
+//    4 waves per SIMD.
 // A column's partial record goes to slot ceil((first item of the segment - first item of the column)/32), so
 // records never collide and the slots a column never uses stay zero (the buffer is zeroed once).
 // d.nchunk = number of slots.
