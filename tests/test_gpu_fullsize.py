@@ -310,6 +310,43 @@ def test_repwvl_table_whose_derived_layers_would_overflow_32_bit_offsets_is_refu
     assert ei.value.code == -1 and "pressure-interpolated table" in str(ei.value)
 
 
+@pytest.mark.parametrize("table", ["Reduced10", "Reduced100"])
+def test_gpu_tau_reproduces_the_tables_own_nodes(pkg, olib, table):
+    """a5 on the GPU against reference-held DATA (the oracle-free twin of
+    tests/test_reference_pins.py::test_read_tau_reproduces_the_tables_own_nodes): columns whose layer temperatures sit
+    exactly on temperature nodes of the table, one absorbing species with mixing ratio 1 -- both optical-depth getters
+    (the reference-form kernel and the production image/prefix route with its merged and padded species slots) must
+    return the 1-D pressure interpolation of the table's own entries: species order, wavelength row, perturbation
+    index, pressure bracket and direction, layer order, number density.  One column per species in ONE ensemble, so
+    that every species varies between columns (nothing merged) and the launch visits all nine slots; a second
+    ensemble of identical columns makes every species shared (everything merged into one slot)."""
+    import test_reference_pins as P
+    rng = np.random.default_rng(37)
+    inp = H.make_inputs(pkg, "repwvl", 9, table=table, perturb=False)
+    t, c = inp["table"], inp["cols"]
+    ci = dict(plevel=c["plevel"])
+    want, scale = [], []
+    for sp in range(9):
+        T, vmr, w, sc = P._node_case(t, ci, rng, sp, olib, 1e-6)   # (tau stays below the production clamp of 1e7)
+        c["Tlayer0"][sp], c["gas"][sp] = T, vmr
+        want.append(w), scale.append(sc)
+    inp["cols"]["rel_hum"][:] = 0.0
+    g = H.gpu_ensemble(pkg, inp)
+    g.set_forcing(inp["solar"], cloud_layer=-1, cloud_tau=0.0)
+    for sp in range(9):
+        for tau in (g.get_tau(sp), g.get_tau_production(sp)):
+            assert np.all(np.abs(tau - want[sp]) <= 1e-12 * scale[sp] + 1e-300), (table, sp)
+    for sp in (0, 1, 6):                      # identical columns: all species shared -> one merged slot (+ H2O's)
+        one = H.make_inputs(pkg, "repwvl", 3, table=table, perturb=False)
+        T, vmr, w, sc = P._node_case(t, ci, rng, sp, olib, 1e-6)
+        one["cols"]["Tlayer0"][:], one["cols"]["gas"][:] = T, vmr
+        g1 = H.gpu_ensemble(pkg, one)
+        g1.set_forcing(one["solar"], cloud_layer=-1, cloud_tau=0.0)
+        for col in (0, 2):
+            for tau in (g1.get_tau(col), g1.get_tau_production(col)):
+                assert np.all(np.abs(tau - w) <= 1e-12 * sc + 1e-300), (table, sp, col)
+
+
 def test_production_tau_outside_the_pressure_grid_measured_bound(pkg, olib):
     """Layers whose mid pressure lies ABOVE the table's largest pressure (110 000 Pa): read_tau's LowerPos walks
     the descending p_grid without a sign change and returns the LAST bracket (the 1e-3 Pa end), so delP is about

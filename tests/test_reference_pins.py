@@ -384,3 +384,45 @@ def test_oracle_lbl_sweep_against_the_reference_pieces_wired_together(ref, olib,
         assert f["E_down"][col].tolist() == Ed.tolist()          # no surface term in E_down: bit for bit
         np.testing.assert_allclose(f["E_up"][col], Eu, rtol=0, atol=1e-12)
         np.testing.assert_allclose(f["dE"][col], dE, rtol=0, atol=1e-12)
+
+
+def _node_case(t, ci, rng, species, olib, vmr_value=1.0):
+    """A column whose layer temperatures sit EXACTLY on temperature nodes of the table (t_ref[ip] + t_pert[k], the very
+    sum read_tau forms at repwvl_thermal.cpp:230), one absorbing species with mixing ratio `vmr_value`: read_tau's bilinear
+    interpolation then collapses, whatever its algebraic form, to the 1-D interpolation in pressure of the table's own
+    entries  xsec[k][species][w][ip], xsec[k][species][w][ip+1]  -- reference-held DATA."""
+    pPa = ci["plevel"] * 100.0
+    midP = (pPa[1:] + pPa[:-1]) / 2                       # top first
+    ip = np.array([olib.orc_lower_pos(_p(t["p_grid"]), t["n_p"], float(m)) for m in midP])
+    k = rng.integers(0, t["n_tpert"], 20)
+    T = t["t_ref"][ip] + t["t_pert"][k]                   # exact nodes
+    vmr = np.zeros((9, 20))
+    vmr[species] = vmr_value
+    delP = (midP - t["p_grid"][ip]) / (t["p_grid"][ip + 1] - t["p_grid"][ip])
+    nd = (pPa[1:] - pPa[:-1]) * 6.02214076e23 / 0.0289647 / 9.80665       # repwvl_thermal.cpp:124-126, 202
+    x = t["xsec"]                                          # [t_pert][species][wvl][p]
+    lo = np.stack([x[k[l], species, :, ip[l]] for l in range(20)], axis=1)      # [wvl][layer]
+    hi = np.stack([x[k[l], species, :, ip[l] + 1] for l in range(20)], axis=1)
+    want = (lo + (hi - lo) * delP[None, :]) * vmr_value * nd[None, :]
+    scale = np.maximum(np.abs(lo), np.abs(hi)) * vmr_value * nd[None, :]
+    return T, vmr, want, scale
+
+
+@pytest.mark.parametrize("table", ["Reduced10", "Reduced100"])
+def test_read_tau_reproduces_the_tables_own_nodes(olib, golden, table):
+    """a5 pinned by reference-held data as far as data can pin it: every INDEX convention of read_tau -- species order
+    (:102-110), wavelength row (the reversals at :206 and :244 cancel), temperature-perturbation index, pressure
+    bracket and its direction on the descending grid, layer order (inputs reversed at :89-99, results stored back top
+    first) and the number density (:202) -- checked against the table entries themselves, for each of the 9 species,
+    random temperature nodes incl. the first and last perturbation.  What this cannot pin is the rounding of the
+    corner-difference form between nodes (:235-241); tolerance 1e-12 of the larger corner."""
+    atm, _ = ol.atm_load(olib, os.path.join(golden, "test.atm"))
+    ci = ol.column_init(olib, atm, 1.0, 1.0)
+    t = ol.read_rtab(os.path.join(golden, f"{table}Forcing.rtab"))
+    rng = np.random.default_rng(31)
+    for species in range(9):
+        for rep in range(3):
+            T, vmr, want, scale = _node_case(t, ci, rng, species, olib)
+            got = _orc_tau(olib, t, ci, T, vmr, cloud=False)
+            assert np.all(np.abs(got - want) <= 1e-12 * scale + 1e-300), (species, rep)
+        assert np.abs(want).max() > 0 or species in ()     # every species has entries in these tables
