@@ -3,6 +3,7 @@
 #   make examples   -> examples/abi_minimal (the C ABI from a plain C++ program)
 #   make oracle     -> the CPU checker (test infrastructure, never linked into the product)
 #   make asan-nc    -> mutation fuzz of the .nc reader under ASan/UBSan (100 000 cases, host code)
+#   make asan-host  -> the same for the .rtab / .atm / ASCII-table / lbl-cache readers (20 000 cases each)
 # `python -m our_first_climate_model_amd.build` does the same from Python (and is what __graft_entry__.build() calls).
 HIPCC     ?= /opt/rocm/bin/hipcc
 ROCM_PATH ?= /opt/rocm
@@ -40,7 +41,12 @@ asan-nc:
 	/tmp/rcm_nc_fuzz tests/golden/Reduced10Forcing.nc 100000 /tmp/rcm_nc_fuzz_scratch.nc \
 	  $(wildcard /root/reference/repwvl_V2.01_cpp/Reduced20Forcing.nc /root/reference/repwvl_V2.01_cpp/Reduced100Forcing.nc)
 
+asan-host:
+	g++ -std=c++17 -O1 -g -fsanitize=address,undefined -fno-sanitize-recover=all -fno-omit-frame-pointer -Iinclude \
+	  -I$(CSRC) -o /tmp/rcm_host_fuzz tests/sanitize/host_fuzz.cpp $(CSRC)/rcm_nc.cpp $(CSRC)/rcm_host.cpp
+	/tmp/rcm_host_fuzz tests/golden/Reduced10Forcing.rtab tests/golden/test.atm 20000 /tmp/rcm_host_fuzz_scratch
+
 clean:
 	rm -f $(LIB) $(MAIN) examples/abi_minimal
 
-.PHONY: all examples oracle asan-nc clean
+.PHONY: all examples oracle asan-nc asan-host clean

@@ -219,6 +219,16 @@ int rcm_ascii_file2xy2D(const char *path, int *nx, int *ny, double **x, double *
   return 0;
 }
 
+// Bytes left in f behind the current position (the readers below size their allocations from header fields of an
+// untrusted file: a header that promises more than the file holds is refused BEFORE anything is allocated).
+static long long bytes_left(FILE *f) {
+  const long here = std::ftell(f);
+  if (here < 0 || std::fseek(f, 0, SEEK_END) != 0) return -1;
+  const long end = std::ftell(f);
+  if (end < 0 || std::fseek(f, here, SEEK_SET) != 0) return -1;
+  return (long long)end - here;
+}
+
 // ---------------------------------------------------------------------------------------------
 // repwvl table: the .rtab blob (tools/flatten_repwvl.py) or the .nc file itself (rcm_nc.cpp).
 // ---------------------------------------------------------------------------------------------
@@ -240,7 +250,12 @@ int rcm_rtab_load(const char *path, long long dims[4], double **blob) {
     return fail(RCM_ERR_FORMAT, std::string("rcm_rtab_load: not an RWVLTAB1 blob: ") + path);
   }
   const size_t nt = d[0], ns = d[1], nw = d[2], np = d[3];
-  const size_t n = np + np + nt + ns * np + nw + nw + nt * ns * nw * np;
+  const size_t n = np + np + nt + ns * np + nw + nw + nt * ns * nw * np;  // (< 2^61 with the limits above: no wrap)
+  const long long have = bytes_left(f);
+  if (have < 0 || (unsigned long long)have / sizeof(double) < n) {
+    std::fclose(f);
+    return fail(RCM_ERR_FORMAT, std::string("rcm_rtab_load: truncated blob: ") + path);
+  }
   double *b = (double *)std::malloc(n * sizeof(double));
   if (!b) {
     std::fclose(f);
@@ -294,20 +309,27 @@ int rcm_lbl_cache_read(const char *path, int *n_nodes, int *nlayer, double **wvl
     return fail(RCM_ERR_FORMAT, std::string("rcm_lbl_cache_read: not an LBLTAB1 file: ") + path);
   }
   const size_t n = (size_t)dims[0], nl = (size_t)dims[1];
+  const long long have = bytes_left(f);
+  if (have < 0 || (unsigned long long)have / sizeof(double) < n + (size_t)RCM_NSPEC_LBL * n * nl) {
+    std::fclose(f);
+    return fail(RCM_ERR_FORMAT, std::string("rcm_lbl_cache_read: truncated file: ") + path);
+  }
   double *w = (double *)std::malloc(n * sizeof(double));
   double *t = (double *)std::malloc((size_t)RCM_NSPEC_LBL * n * nl * sizeof(double));
-  std::vector<double> row(n);
-  bool ok = w && t && std::fread(w, sizeof(double), n, f) == n;
+  double *row = (double *)std::malloc(n * sizeof(double));  // (no exception may cross the C ABI: malloc, not std::vector)
+  bool ok = w && t && row && std::fread(w, sizeof(double), n, f) == n;
   for (size_t s = 0; ok && s < RCM_NSPEC_LBL; ++s)
     for (size_t l = 0; ok && l < nl; ++l) {
-      ok = std::fread(row.data(), sizeof(double), n, f) == n;
+      ok = std::fread(row, sizeof(double), n, f) == n;
       for (size_t b = 0; ok && b < n; ++b) t[(s * n + b) * nl + l] = row[b];
     }
   std::fclose(f);
+  const bool nomem = !w || !t || !row;
+  std::free(row);
   if (!ok) {
     std::free(w);
     std::free(t);
-    return fail(w && t ? RCM_ERR_FORMAT : RCM_ERR_NOMEM, std::string("rcm_lbl_cache_read: truncated or out of memory: ") + path);
+    return fail(nomem ? RCM_ERR_NOMEM : RCM_ERR_FORMAT, std::string("rcm_lbl_cache_read: truncated or out of memory: ") + path);
   }
   *n_nodes = (int)n;
   *nlayer = (int)nl;

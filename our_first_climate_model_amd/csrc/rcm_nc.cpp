@@ -15,6 +15,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <map>
+#include <new>
 #include <string>
 #include <vector>
 
@@ -257,7 +258,12 @@ int nc_table_load(const char *path, long long dims[4], double **blob) {
       std::fclose(fp);
       return fail(RCM_ERR_FORMAT, std::string("rcm_rtab_load: implausible file size: ") + path);
     }
-    f.buf.resize((size_t)n);
+    try {
+      f.buf.resize((size_t)n);
+    } catch (const std::bad_alloc &) {
+      std::fclose(fp);
+      return fail(RCM_ERR_NOMEM, "rcm_rtab_load: out of memory");
+    }
     const bool ok = std::fread(f.buf.data(), 1, (size_t)n, fp) == (size_t)n;
     std::fclose(fp);
     if (!ok) return fail(RCM_ERR_IO, std::string("rcm_rtab_load: read failed: ") + path);
@@ -324,6 +330,8 @@ int nc_table_load(const char *path, long long dims[4], double **blob) {
   } catch (const FormatError &e) {
     return fail(RCM_ERR_FORMAT, std::string("rcm_rtab_load: ") + path + ": unsupported NetCDF-4/HDF5 layout (" + e.what +
                                     "); convert it with tools/flatten_repwvl.py");
+  } catch (const std::bad_alloc &) {  // (no exception may cross the C ABI)
+    return fail(RCM_ERR_NOMEM, "rcm_rtab_load: out of memory");
   }
 }
 
