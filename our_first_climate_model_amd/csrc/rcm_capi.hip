@@ -502,7 +502,7 @@ std::vector<CkptField> ckpt_fields(rcm_ensemble *h) {
 
 extern "C" {
 
-int rcm_create(int ncol, int nlayer, int nangle, int device, void *stream, rcm_ensemble **out) {
+int rcm_create(int ncol, int nlayer, int nangle, int device, void *stream, rcm_ensemble **out) try {
   if (!out) return fail(RCM_ERR_ARG, "rcm_create: out is NULL");
   *out = nullptr;
   if (ncol < 1) return fail(RCM_ERR_ARG, "rcm_create: ncol must be >= 1");
@@ -614,9 +614,9 @@ int rcm_create(int ncol, int nlayer, int nangle, int device, void *stream, rcm_e
   if ((rc = rcm_set_forcing(h, 0.0, 17, 2.0 / 2.0))) return bail(rc);
   *out = h;
   return RCM_OK;
-}
+} RCM_ABI_CATCH
 
-int rcm_destroy(rcm_ensemble *h) {
+int rcm_destroy(rcm_ensemble *h) try {
   if (!h) return fail(RCM_ERR_ARG, "rcm_destroy: NULL handle");
   (void)hipSetDevice(h->device);
   if (h->stream) (void)hipStreamSynchronize(h->stream);
@@ -631,9 +631,9 @@ int rcm_destroy(rcm_ensemble *h) {
   if (h->own_stream && h->stream) (void)hipStreamDestroy(h->stream);
   delete h;
   return RCM_OK;
-}
+} RCM_ABI_CATCH
 
-int rcm_set_grid(rcm_ensemble *h, const double *plevel_hPa) {
+int rcm_set_grid(rcm_ensemble *h, const double *plevel_hPa) try {
   if (!h || !plevel_hPa) return fail(RCM_ERR_ARG, "rcm_set_grid: bad argument");
   if (int rc = use_device(h)) return rc;
   h->plevel.assign(plevel_hPa, plevel_hPa + NLEV);
@@ -650,17 +650,17 @@ int rcm_set_grid(rcm_ensemble *h, const double *plevel_hPa) {
   h->have_grid = true;
   h->img_valid = false;
   return derive_repwvl_layers(h);
-}
+} RCM_ABI_CATCH
 
-int rcm_set_forcing(rcm_ensemble *h, double solar_irr, int cloud_layer, double cloud_tau) {
+int rcm_set_forcing(rcm_ensemble *h, double solar_irr, int cloud_layer, double cloud_tau) try {
   if (!h || cloud_layer < -1 || cloud_layer >= NL) return fail(RCM_ERR_ARG, "rcm_set_forcing: bad argument");
   if (int rc = use_device(h)) return rc;
   std::vector<double> a((size_t)h->ncol, solar_irr), b((size_t)h->ncol, cloud_tau);
   std::vector<int> c((size_t)h->ncol, cloud_layer);
   return rcm_set_column_forcing(h, a.data(), c.data(), b.data());
-}
+} RCM_ABI_CATCH
 
-int rcm_set_column_forcing(rcm_ensemble *h, const double *solar_irr, const int *cloud_layer, const double *cloud_tau) {
+int rcm_set_column_forcing(rcm_ensemble *h, const double *solar_irr, const int *cloud_layer, const double *cloud_tau) try {
   if (!h) return fail(RCM_ERR_ARG, "rcm_set_column_forcing: NULL handle");
   if (cloud_layer)
     for (int c = 0; c < h->ncol; ++c)
@@ -677,10 +677,10 @@ int rcm_set_column_forcing(rcm_ensemble *h, const double *solar_irr, const int *
   HIPCK(hipStreamSynchronize(h->stream));
   h->img_valid = false;  // the cloud row is part of the stored column images (k_pre rewrites them at the next step)
   return RCM_OK;
-}
+} RCM_ABI_CATCH
 
 int rcm_solar_setup_columns(rcm_ensemble *h, const double *tau_s, const double *mu_s, const double *albedo,
-                            int doublings, double g_asym, double daytime, double E_0, double *solar_out) {
+                            int doublings, double g_asym, double daytime, double E_0, double *solar_out) try {
   if (!h || !tau_s || !mu_s || !albedo || doublings < 0)
     return fail(RCM_ERR_ARG, "rcm_solar_setup_columns: bad argument");
   for (int c = 0; c < h->ncol; ++c)
@@ -706,18 +706,18 @@ int rcm_solar_setup_columns(rcm_ensemble *h, const double *tau_s, const double *
   if (e != hipSuccess) return fail(RCM_ERR_HIP, std::string("rcm_solar_setup_columns: ") + hipGetErrorString(e));
   h->img_valid = false;  // k_solar rewrote the cloud optical depths
   return RCM_OK;
-}
+} RCM_ABI_CATCH
 
-int rcm_get_residual(rcm_ensemble *h, double *resid) {
+int rcm_get_residual(rcm_ensemble *h, double *resid) try {
   if (!h || !resid) return fail(RCM_ERR_ARG, "rcm_get_residual: bad argument");
   if (int rc = use_device(h)) return rc;
   HIPCK(hipMemcpyAsync(resid, h->d.resid, (size_t)h->ncol * sizeof(double), hipMemcpyDeviceToHost, h->stream));
   HIPCK(hipStreamSynchronize(h->stream));
   return RCM_OK;
-}
+} RCM_ABI_CATCH
 
 int rcm_run_to_equilibrium(rcm_ensemble *h, double tol_K, int max_steps, int check_every, int *steps_done,
-                           double *residual_K) {
+                           double *residual_K) try {
   if (!h || !(tol_K >= 0) || max_steps < 0 || check_every < 1)
     return fail(RCM_ERR_ARG, "rcm_run_to_equilibrium: bad argument");
   std::vector<double> r((size_t)h->ncol);
@@ -735,11 +735,11 @@ int rcm_run_to_equilibrium(rcm_ensemble *h, double tol_K, int max_steps, int che
   if (steps_done) *steps_done = done;
   if (residual_K) *residual_K = worst;
   return RCM_OK;
-}
+} RCM_ABI_CATCH
 
 int rcm_set_repwvl_tables(rcm_ensemble *h, int n_tpert, int n_species, int n_wvl, int n_p,
                           const double *p_grid, const double *t_ref, const double *t_pert,
-                          const double *wvl, const double *weight, const double *xsec) {
+                          const double *wvl, const double *weight, const double *xsec) try {
   if (!h || !p_grid || !t_ref || !t_pert || !wvl || !weight || !xsec)
     return fail(RCM_ERR_ARG, "rcm_set_repwvl_tables: NULL argument");
   if (n_species != RCM_NSPEC_REPWVL) return fail(RCM_ERR_ARG, "rcm_set_repwvl_tables: n_species must be 9");
@@ -804,10 +804,10 @@ int rcm_set_repwvl_tables(rcm_ensemble *h, int n_tpert, int n_species, int n_wvl
   d.merged_slot = -1;
   h->shared_set = 0;
   return derive_repwvl_layers(h);
-}
+} RCM_ABI_CATCH
 
 int rcm_set_lbl_tables(rcm_ensemble *h, int n_nodes, const double *wvl,
-                       const double *const tabs[RCM_NSPEC_LBL], const double *h2o_ref) {
+                       const double *const tabs[RCM_NSPEC_LBL], const double *h2o_ref) try {
   if (!h || !wvl || !tabs || !h2o_ref) return fail(RCM_ERR_ARG, "rcm_set_lbl_tables: NULL argument");
   if (n_nodes < 2) return fail(RCM_ERR_ARG, "rcm_set_lbl_tables: need at least 2 wavelength nodes");
   for (int s = 0; s < RCM_NSPEC_LBL; ++s)
@@ -853,10 +853,10 @@ int rcm_set_lbl_tables(rcm_ensemble *h, int n_nodes, const double *wvl,
   d.ngas = RCM_NSPEC_LBL;
   d.mode = h->mode = rcm::MODE_LBL;
   return RCM_OK;
-}
+} RCM_ABI_CATCH
 
 int rcm_set_columns(rcm_ensemble *h, const double *Tlayer0, const double *T_surface0,
-                    const double *gas, const double *rel_hum) {
+                    const double *gas, const double *rel_hum) try {
   if (!h || !Tlayer0 || !T_surface0 || !gas || !rel_hum) return fail(RCM_ERR_ARG, "rcm_set_columns: NULL argument");
   if (h->mode == rcm::MODE_NONE) return fail(RCM_ERR_STATE, "rcm_set_columns: set the spectral tables first");
   if (int rc = use_device(h)) return rc;
@@ -878,24 +878,24 @@ int rcm_set_columns(rcm_ensemble *h, const double *Tlayer0, const double *T_surf
   h->have_columns = true;
   h->img_valid = false;
   return RCM_OK;
-}
+} RCM_ABI_CATCH
 
-int rcm_set_spectral_chunks(rcm_ensemble *h, int nchunk) {
+int rcm_set_spectral_chunks(rcm_ensemble *h, int nchunk) try {
   if (!h || nchunk < 0) return fail(RCM_ERR_ARG, "rcm_set_spectral_chunks: bad argument");
   h->user_chunks = nchunk;
   h->d.partial = nullptr;  // re-derive on the next step
   return RCM_OK;
-}
+} RCM_ABI_CATCH
 
-int rcm_get_spectral_chunks(rcm_ensemble *h) {
+int rcm_get_spectral_chunks(rcm_ensemble *h) try {
   if (!h || h->mode == rcm::MODE_NONE) return fail(RCM_ERR_STATE, "rcm_get_spectral_chunks: tables not set");
   if (use_flat(h)) return (h->d.n_wvl + 31) / 32 + 1;
   int nchunk = 0, len = 0;
   choose_chunks(h->ncol, h->d.nspec, h->user_chunks, &nchunk, &len);
   return nchunk;
-}
+} RCM_ABI_CATCH
 
-int rcm_step(rcm_ensemble *h, int nsteps) {
+int rcm_step(rcm_ensemble *h, int nsteps) try {
   if (!h || nsteps < 0) return fail(RCM_ERR_ARG, "rcm_step: bad argument");
   if (h->mode == rcm::MODE_NONE || !h->have_grid || !h->have_columns)
     return fail(RCM_ERR_STATE, "rcm_step: grid, spectral tables and columns must be set first");
@@ -910,10 +910,10 @@ int rcm_step(rcm_ensemble *h, int nsteps) {
   // the last k_post of a call does not go on with the next iteration: d.img is the image of the last sweep
   if (nsteps > 0) h->img_valid = h->mode == rcm::MODE_REPWVL;
   return RCM_OK;
-}
+} RCM_ABI_CATCH
 
 #ifdef RCM_DBG_STAMPS  // profiling builds only; not declared in include/rcm.h
-int rcm_dbg_stamps(rcm_ensemble *h, unsigned long long *out, int n) {
+int rcm_dbg_stamps(rcm_ensemble *h, unsigned long long *out, int n) try {
   if (!h->d.dbg) {
     HIPCK(hipMalloc((void **)&h->d.dbg, (size_t)n * sizeof(unsigned long long)));
     HIPCK(hipMemset(h->d.dbg, 0, (size_t)n * sizeof(unsigned long long)));
@@ -923,12 +923,12 @@ int rcm_dbg_stamps(rcm_ensemble *h, unsigned long long *out, int n) {
   HIPCK(hipStreamSynchronize(h->stream));
   HIPCK(hipMemcpy(out, h->d.dbg, (size_t)n * sizeof(unsigned long long), hipMemcpyDeviceToHost));
   return RCM_OK;
-}
+} RCM_ABI_CATCH
 #endif
 
 #ifdef RCM_WITH_VARIANTS  // test-side build only; not declared in include/rcm.h
 // Point-by-point evaluation of an elementary device function (k_eval_device_fn, rcm_variants.hpp); host arrays.
-int rcm_dbg_eval(int fn, int n, const double *a, const double *b, const double *c, double *out) {
+int rcm_dbg_eval(int fn, int n, const double *a, const double *b, const double *c, double *out) try {
   if (n < 1 || !a || !b || !c || !out || fn < 0 || fn > 5) return fail(RCM_ERR_ARG, "rcm_dbg_eval: bad argument");
   double *d = nullptr;
   const size_t bytes = (size_t)n * sizeof(double);
@@ -945,26 +945,26 @@ int rcm_dbg_eval(int fn, int n, const double *a, const double *b, const double *
   (void)hipFree(d);
   if (e != hipSuccess) return fail(RCM_ERR_HIP, std::string("rcm_dbg_eval: ") + hipGetErrorString(e));
   return RCM_OK;
-}
+} RCM_ABI_CATCH
 
-int rcm_set_step_fusion(rcm_ensemble *h, int mode) {
+int rcm_set_step_fusion(rcm_ensemble *h, int mode) try {
   if (!h || mode < -1 || mode > 1) return fail(RCM_ERR_ARG, "rcm_set_step_fusion: mode must be -1 (automatic), 0 or 1");
   h->fusion = mode;
   return RCM_OK;
-}
+} RCM_ABI_CATCH
 
-int rcm_get_step_fusion(rcm_ensemble *h) {
+int rcm_get_step_fusion(rcm_ensemble *h) try {
   if (!h || h->mode == rcm::MODE_NONE) return fail(RCM_ERR_STATE, "rcm_get_step_fusion: tables not set");
   return choose_lpc(h);
-}
+} RCM_ABI_CATCH
 #endif
 
-int rcm_sync(rcm_ensemble *h) {
+int rcm_sync(rcm_ensemble *h) try {
   if (!h) return fail(RCM_ERR_ARG, "rcm_sync: NULL handle");
   if (int rc = use_device(h)) return rc;
   HIPCK(hipStreamSynchronize(h->stream));
   return RCM_OK;
-}
+} RCM_ABI_CATCH
 
 static int copy_out(rcm_ensemble *h, void *dst, const void *src, size_t bytes) {
   if (!dst) return RCM_OK;
@@ -972,7 +972,7 @@ static int copy_out(rcm_ensemble *h, void *dst, const void *src, size_t bytes) {
   return RCM_OK;
 }
 
-int rcm_get_state(rcm_ensemble *h, double *Tlayer, double *T_surface, float *time_h, double *timestep) {
+int rcm_get_state(rcm_ensemble *h, double *Tlayer, double *T_surface, float *time_h, double *timestep) try {
   if (!h) return fail(RCM_ERR_ARG, "rcm_get_state: NULL handle");
   if (int rc = use_device(h)) return rc;
   int rc = 0;
@@ -983,9 +983,9 @@ int rcm_get_state(rcm_ensemble *h, double *Tlayer, double *T_surface, float *tim
   if (rc) return rc;
   HIPCK(hipStreamSynchronize(h->stream));
   return RCM_OK;
-}
+} RCM_ABI_CATCH
 
-int rcm_get_fluxes(rcm_ensemble *h, double *E_down, double *E_up, double *dE) {
+int rcm_get_fluxes(rcm_ensemble *h, double *E_down, double *E_up, double *dE) try {
   if (!h) return fail(RCM_ERR_ARG, "rcm_get_fluxes: NULL handle");
   if (int rc = use_device(h)) return rc;
   int rc = 0;
@@ -995,9 +995,9 @@ int rcm_get_fluxes(rcm_ensemble *h, double *E_down, double *E_up, double *dE) {
   if (rc) return rc;
   HIPCK(hipStreamSynchronize(h->stream));
   return RCM_OK;
-}
+} RCM_ABI_CATCH
 
-int rcm_get_profile(rcm_ensemble *h, int col, double *Tlayer_adj, double *theta, float *time_h) {
+int rcm_get_profile(rcm_ensemble *h, int col, double *Tlayer_adj, double *theta, float *time_h) try {
   if (!h || col < 0 || col >= h->ncol) return fail(RCM_ERR_ARG, "rcm_get_profile: bad argument");
   if (!h->have_grid || !h->have_columns) return fail(RCM_ERR_STATE, "rcm_get_profile: grid/columns not set");
   if (int rc = use_device(h)) return rc;
@@ -1010,14 +1010,14 @@ int rcm_get_profile(rcm_ensemble *h, int col, double *Tlayer_adj, double *theta,
   if (rc) return rc;
   HIPCK(hipStreamSynchronize(h->stream));
   return RCM_OK;
-}
+} RCM_ABI_CATCH
 
-int rcm_nspectral(rcm_ensemble *h) {
+int rcm_nspectral(rcm_ensemble *h) try {
   if (!h || h->mode == rcm::MODE_NONE) return fail(RCM_ERR_STATE, "rcm_nspectral: tables not set");
   return h->d.nspec;
-}
+} RCM_ABI_CATCH
 
-int rcm_get_tau(rcm_ensemble *h, int col, double *tau) {
+int rcm_get_tau(rcm_ensemble *h, int col, double *tau) try {
   if (!h || !tau || col < 0 || col >= h->ncol) return fail(RCM_ERR_ARG, "rcm_get_tau: bad argument");
   if (h->mode == rcm::MODE_NONE || !h->have_grid || !h->have_columns)
     return fail(RCM_ERR_STATE, "rcm_get_tau: grid, tables and columns must be set first");
@@ -1032,9 +1032,9 @@ int rcm_get_tau(rcm_ensemble *h, int col, double *tau) {
   (void)hipFree(buf);
   if (e != hipSuccess) return fail(RCM_ERR_HIP, std::string("rcm_get_tau: ") + hipGetErrorString(e));
   return RCM_OK;
-}
+} RCM_ABI_CATCH
 
-int rcm_get_tau_production(rcm_ensemble *h, int col, double *tau) {
+int rcm_get_tau_production(rcm_ensemble *h, int col, double *tau) try {
   if (!h || !tau || col < 0 || col >= h->ncol) return fail(RCM_ERR_ARG, "rcm_get_tau_production: bad argument");
   if (h->mode == rcm::MODE_NONE || !h->have_grid || !h->have_columns)
     return fail(RCM_ERR_STATE, "rcm_get_tau_production: grid, tables and columns must be set first");
@@ -1060,18 +1060,18 @@ int rcm_get_tau_production(rcm_ensemble *h, int col, double *tau) {
   (void)hipFree(buf);
   if (e != hipSuccess) return fail(RCM_ERR_HIP, std::string("rcm_get_tau_production: ") + hipGetErrorString(e));
   return RCM_OK;
-}
+} RCM_ABI_CATCH
 
-int rcm_get_gas(rcm_ensemble *h, double *gas) {
+int rcm_get_gas(rcm_ensemble *h, double *gas) try {
   if (!h || !gas) return fail(RCM_ERR_ARG, "rcm_get_gas: bad argument");
   if (!h->have_columns) return fail(RCM_ERR_STATE, "rcm_get_gas: columns not set");
   if (int rc = use_device(h)) return rc;
   if (int rc = copy_out(h, gas, h->d.gas, (size_t)h->ncol * h->d.ngas * NL * sizeof(double))) return rc;
   HIPCK(hipStreamSynchronize(h->stream));
   return RCM_OK;
-}
+} RCM_ABI_CATCH
 
-int rcm_pack_state(rcm_ensemble *h, void *dev_out) {
+int rcm_pack_state(rcm_ensemble *h, void *dev_out) try {
   if (!h || !dev_out) return fail(RCM_ERR_ARG, "rcm_pack_state: bad argument");
   if (!h->have_columns) return fail(RCM_ERR_STATE, "rcm_pack_state: columns not set");
   if (int rc = use_device(h)) return rc;
@@ -1079,7 +1079,7 @@ int rcm_pack_state(rcm_ensemble *h, void *dev_out) {
   hipLaunchKernelGGL(rcm::k_pack, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, h->stream, h->d, (double *)dev_out);
   HIPCK(hipGetLastError());
   return RCM_OK;
-}
+} RCM_ABI_CATCH
 
 // ncclAllGather of the caller's RCCL.  The communicator comes from the caller, so the call must go to the
 // very librccl the caller created it with: the symbol is looked up in the running process (global scope
@@ -1103,7 +1103,7 @@ allgather_fn find_allgather(std::string *where) {
 }
 }  // namespace
 
-int rcm_gather(rcm_ensemble *h, void *nccl_comm, void *dev_recv, int ncol_pad) {
+int rcm_gather(rcm_ensemble *h, void *nccl_comm, void *dev_recv, int ncol_pad) try {
   if (!h || !nccl_comm || !dev_recv || ncol_pad < h->ncol)
     return fail(RCM_ERR_ARG, "rcm_gather: bad argument (ncol_pad must be >= this handle's ncol)");
   if (!h->have_columns) return fail(RCM_ERR_STATE, "rcm_gather: columns not set");
@@ -1130,9 +1130,9 @@ int rcm_gather(rcm_ensemble *h, void *nccl_comm, void *dev_recv, int ncol_pad) {
   const int nrc = allgather(h->gather_send, dev_recv, blk, /* ncclFloat64 */ 8, nccl_comm, h->stream);
   if (nrc != 0) return fail(RCM_ERR_HIP, "rcm_gather: ncclAllGather (" + where + ") returned " + std::to_string(nrc));
   return RCM_OK;
-}
+} RCM_ABI_CATCH
 
-int rcm_checkpoint_save(rcm_ensemble *h, const char *path) {
+int rcm_checkpoint_save(rcm_ensemble *h, const char *path) try {
   if (!h || !path) return fail(RCM_ERR_ARG, "rcm_checkpoint_save: bad argument");
   if (!h->have_columns) return fail(RCM_ERR_STATE, "rcm_checkpoint_save: columns not set");
   if (int rc = use_device(h)) return rc;
@@ -1153,9 +1153,9 @@ int rcm_checkpoint_save(rcm_ensemble *h, const char *path) {
   }
   ok = (std::fclose(f) == 0) && ok;
   return ok ? RCM_OK : fail(RCM_ERR_IO, std::string("rcm_checkpoint_save: write failed: ") + path);
-}
+} RCM_ABI_CATCH
 
-int rcm_checkpoint_load(rcm_ensemble *h, const char *path) {
+int rcm_checkpoint_load(rcm_ensemble *h, const char *path) try {
   if (!h || !path) return fail(RCM_ERR_ARG, "rcm_checkpoint_load: bad argument");
   if (h->mode == rcm::MODE_NONE || !h->have_grid)
     return fail(RCM_ERR_STATE, "rcm_checkpoint_load: set the grid and the spectral tables first");
@@ -1202,16 +1202,16 @@ int rcm_checkpoint_load(rcm_ensemble *h, const char *path) {
   h->have_columns = true;
   h->img_valid = false;  // (classify_species cleared the images; the next step or the optical-depth getter rebuilds them)
   return RCM_OK;
-}
+} RCM_ABI_CATCH
 
-int rcm_set_rt_timing(rcm_ensemble *h, int enable) {
+int rcm_set_rt_timing(rcm_ensemble *h, int enable) try {
   if (!h) return fail(RCM_ERR_ARG, "rcm_set_rt_timing: NULL handle");
   h->timing = enable != 0;
   h->events_used = 0;
   return RCM_OK;
-}
+} RCM_ABI_CATCH
 
-int rcm_get_rt_timing(rcm_ensemble *h, double *ms_total, int *launches) {
+int rcm_get_rt_timing(rcm_ensemble *h, double *ms_total, int *launches) try {
   if (!h) return fail(RCM_ERR_ARG, "rcm_get_rt_timing: NULL handle");
   if (int rc = use_device(h)) return rc;
   HIPCK(hipStreamSynchronize(h->stream));
@@ -1225,6 +1225,6 @@ int rcm_get_rt_timing(rcm_ensemble *h, double *ms_total, int *launches) {
   if (launches) *launches = (int)h->events_used;
   h->events_used = 0;
   return RCM_OK;
-}
+} RCM_ABI_CATCH
 
 }  // extern "C"

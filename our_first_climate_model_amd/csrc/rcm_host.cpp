@@ -49,7 +49,7 @@ void rcm_free(void *p) { std::free(p); }
 // run of parseable numbers, one per column; rows with none are skipped by construction.
 // ---------------------------------------------------------------------------------------------
 int rcm_atm_load(const char *path, int nlevel_max, double *cols, int *nlevel_out,
-                 int *ncols_found) {
+                 int *ncols_found) try {
   if (!path || !cols || nlevel_max < 2) return fail(RCM_ERR_ARG, "rcm_atm_load: bad argument");
   std::ifstream in(path);
   if (!in) return fail(RCM_ERR_IO, std::string("rcm_atm_load: cannot open ") + path);
@@ -82,7 +82,7 @@ int rcm_atm_load(const char *path, int nlevel_max, double *cols, int *nlevel_out
   if (nlevel_out) *nlevel_out = nrow;
   if (ncols_found) *ncols_found = maxc;
   return RCM_OK;
-}
+} RCM_ABI_CATCH
 
 // ---------------------------------------------------------------------------------------------
 // Column initialisation: main.cpp:439-485.
@@ -93,7 +93,7 @@ static double magnus_hPa(double T) {  // main.cpp:277-279
 
 int rcm_column_init(int nlevel, const double *a, double co2_factor, double rh_scale,
                     double *plevel, double *player, double *Tlayer, double *conv, double *vmr9,
-                    double *rel_hum) {
+                    double *rel_hum) try {
   if (nlevel < 2 || !a || !plevel || !player || !Tlayer || !conv || !vmr9 || !rel_hum)
     return fail(RCM_ERR_ARG, "rcm_column_init: bad argument");
   const int nl = nlevel - 1;
@@ -123,13 +123,13 @@ int rcm_column_init(int nlevel, const double *a, double co2_factor, double rh_sc
     conv[i] = std::pow(1000.0 / player[i], kappa);  // main.cpp:474
   }
   return RCM_OK;
-}
+} RCM_ABI_CATCH
 
 // ---------------------------------------------------------------------------------------------
 // Solar set-up: main.cpp:214-264 (runs once; O(doublings) flops; stays on the host).
 // ---------------------------------------------------------------------------------------------
 int rcm_solar_setup(double tau_s, double mu_s, int doublings, double g_asym, double albedo,
-                    double daytime, double E_0, double out[7]) {
+                    double daytime, double E_0, double out[7]) try {
   if (!out || doublings < 0 || !(mu_s > 0)) return fail(RCM_ERR_ARG, "rcm_solar_setup: bad argument");
   // thin starting layer, main.cpp:216-227
   double dtau = (1 - g_asym) * tau_s / std::pow(2, doublings);
@@ -148,11 +148,11 @@ int rcm_solar_setup(double tau_s, double mu_s, int doublings, double g_asym, dou
   out[0] = r_dir, out[1] = s_dir, out[2] = t_dir, out[3] = r, out[4] = t, out[5] = r_total;
   out[6] = daytime * E_0 * mu_s * (1 - r_total);  // main.cpp:260
   return RCM_OK;
-}
+} RCM_ABI_CATCH
 
-int rcm_default_solar(double out[7]) {  // main.cpp:69, 86-91
+int rcm_default_solar(double out[7]) try {  // main.cpp:69, 86-91
   return rcm_solar_setup(2.0, std::cos(60 * M_PI / 180.0), 20, 0.85, 0.12, (double)0.5f, 1361.0, out);
-}
+} RCM_ABI_CATCH
 
 // ---------------------------------------------------------------------------------------------
 // ASCII matrix loader with ASCII_file2xy2D semantics (lbl.arts/ascii.cpp:1631-1691):
@@ -164,23 +164,28 @@ int rcm_default_solar(double out[7]) {  // main.cpp:69, 86-91
 //  * tokens go through strtod: a non-number reads as 0 (ascii.cpp:1405-1417).
 // One pass over the file instead of the reference's count/allocate-strings/re-read.
 // ---------------------------------------------------------------------------------------------
-int rcm_ascii_file2xy2D(const char *path, int *nx, int *ny, double **x, double **y) {
+int rcm_ascii_file2xy2D(const char *path, int *nx, int *ny, double **x, double **y) try {
   if (!path || !nx || !ny || !x || !y) return fail(RCM_ERR_ARG, "rcm_ascii_file2xy2D: bad argument");
   FILE *f = std::fopen(path, "r");
   if (!f) {
     std::fprintf(stderr, "Error, file '%s' not found!\n", path);  // ascii.cpp:247
     return fail(-1, std::string("file not found: ") + path);      // ASCIIFILE_NOT_FOUND
   }
+  struct Owner {  // closes the file and frees the line buffer on every way out, an exception included
+    FILE *f;
+    char *line = nullptr;
+    ~Owner() {
+      std::free(line);
+      if (f) std::fclose(f);
+    }
+  } own{f};
   std::vector<double> vals;
   // the reference reads with fgets(line, MAX_LENGTH_OF_LINE, f) (ascii.cpp:155,233,255): a physical line of
   // 1 048 575 characters or more is cut there and continues as the next "row" (a number across the cut splits
   // in two); same buffer size and same call here so that such a file fails or parses exactly as it does there
   constexpr int kMaxLine = 1048576;
-  char *line = (char *)std::malloc((size_t)kMaxLine + 1);
-  if (!line) {
-    std::fclose(f);
-    return fail(-2, "no memory");  // ASCII_NO_MEMORY
-  }
+  char *line = own.line = (char *)std::malloc((size_t)kMaxLine + 1);
+  if (!line) return fail(-2, "no memory");  // ASCII_NO_MEMORY
   int rows = 0, min_col = INT_MAX, max_col = 0;
   while (std::fgets(line, kMaxLine, f) != nullptr) {
     int ncol = 0;
@@ -197,8 +202,6 @@ int rcm_ascii_file2xy2D(const char *path, int *nx, int *ny, double **x, double *
       if (ncol > max_col) max_col = ncol;
     }
   }
-  std::free(line);
-  std::fclose(f);
   if (min_col != max_col) return fail(-5, "not a rectangular matrix");  // NOT_A_RECTANGULAR_MATRIX
   const int ncy = max_col - 1;
   double *xs = (double *)std::calloc((size_t)rows, sizeof(double));
@@ -217,6 +220,8 @@ int rcm_ascii_file2xy2D(const char *path, int *nx, int *ny, double **x, double *
   *x = xs;
   *y = ys;
   return 0;
+} catch (const std::bad_alloc &) {
+  return fail(-2, "no memory");  // ASCII_NO_MEMORY, the reference's own code (no exception may cross the C ABI)
 }
 
 // Bytes left in f behind the current position (the readers below size their allocations from header fields of an
@@ -232,7 +237,7 @@ static long long bytes_left(FILE *f) {
 // ---------------------------------------------------------------------------------------------
 // repwvl table: the .rtab blob (tools/flatten_repwvl.py) or the .nc file itself (rcm_nc.cpp).
 // ---------------------------------------------------------------------------------------------
-int rcm_rtab_load(const char *path, long long dims[4], double **blob) {
+int rcm_rtab_load(const char *path, long long dims[4], double **blob) try {
   if (!path || !dims || !blob) return fail(RCM_ERR_ARG, "rcm_rtab_load: bad argument");
   FILE *f = std::fopen(path, "rb");
   if (!f) return fail(RCM_ERR_IO, std::string("rcm_rtab_load: cannot open ") + path);
@@ -270,14 +275,14 @@ int rcm_rtab_load(const char *path, long long dims[4], double **blob) {
   for (int i = 0; i < 4; ++i) dims[i] = d[i];
   *blob = b;
   return RCM_OK;
-}
+} RCM_ABI_CATCH
 
 // ---------------------------------------------------------------------------------------------
 // Binary cache of the lbl tables: "LBLTAB1\0", int64 n_nodes, int64 nlayer, wvl[n_nodes],
 // tab[5][nlayer][n_nodes] (node fastest).
 // ---------------------------------------------------------------------------------------------
 int rcm_lbl_cache_write(const char *path, int n_nodes, int nlayer, const double *wvl,
-                        const double *const tabs[RCM_NSPEC_LBL]) {
+                        const double *const tabs[RCM_NSPEC_LBL]) try {
   if (!path || !wvl || !tabs || n_nodes < 2 || nlayer < 1) return fail(RCM_ERR_ARG, "rcm_lbl_cache_write: bad argument");
   for (int s = 0; s < RCM_NSPEC_LBL; ++s)
     if (!tabs[s]) return fail(RCM_ERR_ARG, "rcm_lbl_cache_write: NULL table");
@@ -294,9 +299,9 @@ int rcm_lbl_cache_write(const char *path, int n_nodes, int nlayer, const double 
     }
   ok = (std::fclose(f) == 0) && ok;
   return ok ? RCM_OK : fail(RCM_ERR_IO, std::string("rcm_lbl_cache_write: write failed: ") + path);
-}
+} RCM_ABI_CATCH
 
-int rcm_lbl_cache_read(const char *path, int *n_nodes, int *nlayer, double **wvl, double **tabs) {
+int rcm_lbl_cache_read(const char *path, int *n_nodes, int *nlayer, double **wvl, double **tabs) try {
   if (!path || !n_nodes || !nlayer || !wvl || !tabs) return fail(RCM_ERR_ARG, "rcm_lbl_cache_read: bad argument");
   FILE *f = std::fopen(path, "rb");
   if (!f) return fail(RCM_ERR_IO, std::string("rcm_lbl_cache_read: cannot open ") + path);
@@ -336,12 +341,12 @@ int rcm_lbl_cache_read(const char *path, int *n_nodes, int *nlayer, double **wvl
   *wvl = w;
   *tabs = t;
   return RCM_OK;
-}
+} RCM_ABI_CATCH
 
 // ---------------------------------------------------------------------------------------------
 // output.txt formats: main.cpp:513-519, 528 (banner) and :109-110 (rows).
 // ---------------------------------------------------------------------------------------------
-int rcm_write_banner(void *fp, double tau_s, double mu_s, const double solar[7]) {
+int rcm_write_banner(void *fp, double tau_s, double mu_s, const double solar[7]) try {
   FILE *f = (FILE *)fp;
   if (!f || !solar) return fail(RCM_ERR_ARG, "rcm_write_banner: bad argument");
   std::fprintf(f, "\n ===================new run===================== \n");
@@ -352,15 +357,15 @@ int rcm_write_banner(void *fp, double tau_s, double mu_s, const double solar[7])
   std::fprintf(f, "solar irradiance: %f \n", solar[6]);
   std::fprintf(f, "layer,player,Tlayer,theta,time\n");
   return RCM_OK;
-}
+} RCM_ABI_CATCH
 
 int rcm_write_profile(void *fp, int nlayer, const double *player, const double *Tlayer,
-                      const double *theta, float time_h) {
+                      const double *theta, float time_h) try {
   FILE *f = (FILE *)fp;
   if (!f || !player || !Tlayer || !theta) return fail(RCM_ERR_ARG, "rcm_write_profile: bad argument");
   for (int i = 0; i < nlayer; ++i)
     std::fprintf(f, "%d,%f,%f,%f,%f\n", i, player[i], Tlayer[i], theta[i], time_h);
   return RCM_OK;
-}
+} RCM_ABI_CATCH
 
 }  // extern "C"
