@@ -426,3 +426,57 @@ def test_read_tau_reproduces_the_tables_own_nodes(olib, golden, table):
             got = _orc_tau(olib, t, ci, T, vmr, cloud=False)
             assert np.all(np.abs(got - want) <= 1e-12 * scale + 1e-300), (species, rep)
         assert np.abs(want).max() > 0 or species in ()     # every species has entries in these tables
+
+
+def test_oracle_against_the_committed_reference_vectors(olib, golden):
+    """The same pin WITHOUT the reference tree or oracle/_ref: tests/golden/ref_main_vectors.npz holds seeded inputs
+    and the outputs of the reference's own compiled functions (tools/make_ref_vectors.py, run once where the
+    reference tree is; data only).  The oracle must reproduce every number bit for bit: Planck, radiative_transfer on 40
+    random cases, time step + thermodynamics, adjustment + feedback, magnus, solar set-up, constants, LowerPos, and
+    the state / fluxes at iterations 0, 1, 2, 10, 50, 100 of the 101-iteration chain for Reduced10 and Reduced100.
+    Never skips."""
+    v = np.load(os.path.join(golden, "ref_main_vectors.npz"))
+    wvl, wgt, T = v["planck_in"]
+    assert [olib.orc_planck_mono(float(a), float(b), float(c)) for a, b, c in zip(wvl, wgt, T)] == v["planck_out"].tolist()
+    for case in range(int(v["rt_cases"][0])):
+        Ts, solar = v[f"rt{case}_scalars"]
+        got = _orc_rt(olib, v[f"rt{case}_tau"], v[f"rt{case}_wvl"], v[f"rt{case}_weight"], v[f"rt{case}_T"], Ts, solar)
+        assert np.concatenate(got).tolist() == v[f"rt{case}_out"].tolist(), case
+    conv = np.ascontiguousarray(v["step_conv"])
+    for dE, Tl, want in zip(v["step_dE"], v["step_T"], v["step_out"]):
+        dE, Tn, Ts = np.ascontiguousarray(dE), np.ascontiguousarray(Tl).copy(), np.zeros(1)
+        dt = olib.orc_calculate_timestep(50.0, _p(dE), 20)
+        olib.orc_thermodynamics(_p(Tn), 20, 50.0, _p(dE), dt, _p(Ts), _p(conv))
+        assert [dt, Ts[0]] + Tn.tolist() == want.tolist()
+    conv, rh, pl = (np.ascontiguousarray(v[k]) for k in ("adj_conv", "adj_rel_hum", "adj_player"))
+    for Tl, want in zip(v["adj_T"], v["adj_out"]):
+        Ta, th, h2o = np.ascontiguousarray(Tl).copy(), np.zeros(20), np.zeros(20)
+        olib.orc_convective_adjustment(_p(Ta), _p(th), _p(conv), 20)
+        olib.orc_water_vapor_feedback(_p(Ta), _p(rh), _p(pl), _p(h2o), 20)
+        assert np.concatenate([Ta, th, h2o]).tolist() == want.tolist()
+    assert [olib.orc_magnus(float(t)) for t in v["magnus_in"]] == v["magnus_out"].tolist()
+    sol = np.zeros(7)
+    olib.orc_default_solar(_p(sol))
+    assert sol.tolist() == v["solar_out"].tolist()
+    c = v["consts_out"]
+    assert (c[8], c[9], c[10], c[12], c[18]) == (20, 21, 30, 2.0, 17)
+    for i in range(int(v["lp_cases"][0])):
+        g = np.ascontiguousarray(v[f"lp{i}_grid"])
+        assert [olib.orc_lower_pos(_p(g), g.size, float(x)) for x in v[f"lp{i}_x"]] == v[f"lp{i}_out"].tolist(), i
+    atm, _ = ol.atm_load(olib, os.path.join(golden, "test.atm"))
+    ci = ol.column_init(olib, atm, 1.0, 1.0)
+    for table in ("Reduced10", "Reduced100"):
+        e = ol.OracleEnsemble(olib, 1)
+        e.set_grid(ci["plevel"])
+        e.set_forcing(sol[6])
+        e.set_repwvl_tables(ol.read_rtab(os.path.join(golden, f"{table}Forcing.rtab")))
+        e.set_columns(ci["Tlayer"][None], np.array([288.2]), ci["vmr9"][None], ci["rel_hum"][None])
+        done = 0
+        for row in v[f"chain_{table}"]:
+            i = int(row[0])
+            e.step(i + 1 - done)
+            done = i + 1
+            s, f = e.get_state(), e.get_fluxes()
+            got = np.concatenate([[i, s["timestep"][0], s["T_surface"][0]], s["Tlayer"][0], f["E_down"][0], f["E_up"][0],
+                                  f["dE"][0]])
+            assert got.tolist() == row.tolist(), (table, i)

@@ -1,0 +1,135 @@
+#!/usr/bin/env python3
+"""Writes tests/golden/ref_main_vectors.npz: inputs and OUTPUTS OF THE REFERENCE'S OWN COMPILED CODE
+(oracle/_ref/libref_main.so = /root/reference/main.cpp:12-21,25-344 piped unedited into g++, oracle/Makefile) for
+the functions on the hot path, so that the oracle stays pinned in a checkout that has no reference tree (and no
+oracle/_ref): tests/test_reference_pins.py::test_oracle_against_the_committed_reference_vectors compares the oracle
+with these numbers bit for bit.  Data only: seeded inputs, the reference's outputs.  Needs the reference tree once:
+
+    make -C oracle && python tools/make_ref_vectors.py
+"""
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import oracle_lib as ol  # noqa: E402
+
+_p = ol._p
+ref = ol.load_ref_main()
+lp = ol.load_ref_lowerpos()
+assert ref is not None and lp is not None, "build oracle/_ref first (make -C oracle, reference tree present)"
+olib = ol.load()  # only for the inputs that come from the atmosphere file and read_tau (a5, not a reference output)
+rng = np.random.default_rng(20260104)
+out = {}
+
+# a1: Planck, scalar overload (main.cpp:197-204)
+n = 400
+wvl = np.exp(rng.uniform(np.log(300.0), np.log(5e5), n))
+wgt = rng.normal(size=n) * 10 ** rng.uniform(-3, 6, n)
+T = np.where(rng.random(n) < 0.9, rng.uniform(100.0, 400.0, n), 10 ** rng.uniform(-1, 4, n))
+out["planck_in"] = np.stack([wvl, wgt, T])
+out["planck_out"] = np.array([ref.ref_cplkavg_scalar(float(a), float(b), float(c)) for a, b, c in zip(wvl, wgt, T)])
+
+# a2-a4: radiative_transfer (main.cpp:320-344) on random cases, 1..24 wavelengths
+cases = []
+for case in range(40):
+    nw = int(rng.integers(1, 25))
+    tau = 10 ** rng.uniform(-8, np.log10(3e4), (nw, 20))
+    w = np.sort(np.exp(rng.uniform(np.log(3000.0), np.log(2e5), nw)))
+    wt = rng.normal(size=nw) * 10 ** rng.uniform(0, 5.6, nw)
+    wt[rng.integers(0, nw)] = -46250.7
+    Tl = rng.uniform(180.0, 320.0, 20)
+    Ts, solar = float(rng.uniform(250.0, 330.0)), float(rng.uniform(0.0, 400.0))
+    Ed, Eu, dE = ol.ref_radiative_transfer(ref, tau, w, wt, Tl, Ts, solar)
+    out[f"rt{case}_tau"], out[f"rt{case}_wvl"], out[f"rt{case}_weight"], out[f"rt{case}_T"] = tau, w, wt, Tl
+    out[f"rt{case}_scalars"] = np.array([Ts, solar])
+    out[f"rt{case}_out"] = np.concatenate([Ed, Eu, dE])
+out["rt_cases"] = np.array([40])
+
+# a6 + a7: time step and thermodynamics (main.cpp:156-176)
+conv = (1000.0 / (np.arange(20) * 50.0 + 25.0)) ** (2.0 / 7.0)
+dEs, Ts_in, res = [], [], []
+for case in range(200):
+    dE = rng.normal(size=20) * 10 ** rng.uniform(-3, 3)
+    if case % 5 == 0:
+        dE = -np.abs(dE)
+    if case % 11 == 0:
+        dE *= 1e-4
+    Tl = rng.uniform(180.0, 320.0, 20)
+    dt = ref.ref_calculate_timestep(50.0, _p(dE))
+    Tn = Tl.copy()
+    Ts = ref.ref_thermodynamics(_p(Tn), 50.0, _p(dE), dt, _p(conv))
+    dEs.append(dE), Ts_in.append(Tl), res.append(np.concatenate([[dt, Ts], Tn]))
+out["step_dE"], out["step_T"], out["step_conv"], out["step_out"] = np.array(dEs), np.array(Ts_in), conv, np.array(res)
+
+# a8: adjustment (main.cpp:536-540), feedback (:277-289), magnus
+atm, _ = ol.atm_load(olib, os.path.join(ROOT, "tests", "golden", "test.atm"))
+ci = ol.column_init(olib, atm, 1.0, 1.0)
+Tin, res = [], []
+for case in range(200):
+    Tl = ci["Tlayer"] + rng.normal(size=20) * (0.0 if case == 0 else 10 ** rng.uniform(-6, 1.5))
+    if case % 9 == 0:
+        Tl[5] = Tl[6] * ci["conv"][6] / ci["conv"][5]
+    Ta, th, v = Tl.copy(), np.zeros(20), np.zeros(20)
+    ref.ref_convective_adjustment(_p(Ta), _p(th), _p(ci["conv"]))
+    ref.ref_water_vapor_feedback(_p(Ta), _p(ci["rel_hum"]), _p(ci["player"]), _p(v))
+    Tin.append(Tl), res.append(np.concatenate([Ta, th, v]))
+out["adj_T"], out["adj_out"] = np.array(Tin), np.array(res)
+out["adj_conv"], out["adj_rel_hum"], out["adj_player"] = ci["conv"], ci["rel_hum"], ci["player"]
+mT = np.concatenate([np.linspace(150.0, 350.0, 201), [29.0, 30.11, 30.12, 1e3]])
+out["magnus_in"], out["magnus_out"] = mT, np.array([ref.ref_magnus(float(t)) for t in mT])
+
+# solar set-up and constants (main.cpp:66-91, 214-264)
+sol, cst = np.zeros(7), np.zeros(20)
+ref.ref_solar(_p(sol)), ref.ref_consts(_p(cst))
+out["solar_out"], out["consts_out"] = sol, cst
+
+# a5: LowerPos (repwvl_thermal.cpp:19-45)
+t = ol.read_rtab(os.path.join(ROOT, "tests", "golden", "Reduced10Forcing.rtab"))
+grids = [t["p_grid"], t["t_ref"][7] + t["t_pert"], t["t_ref"][30] + t["t_pert"]]
+for _ in range(12):
+    g = np.sort(rng.normal(size=int(rng.integers(2, 12)))) * (1 if rng.random() < 0.5 else -1)
+    grids.append(np.ascontiguousarray(g))
+for i, g in enumerate(grids):
+    g = np.ascontiguousarray(g, dtype=np.float64)
+    xs = np.concatenate([g, (g[:-1] + g[1:]) / 2, [g.min() - 1.0, g.max() + 1.0],
+                         rng.uniform(g.min() - 0.1 * np.ptp(g) - 1e-9, g.max() + 0.1 * np.ptp(g) + 1e-9, 30)])
+    out[f"lp{i}_grid"], out[f"lp{i}_x"] = g, xs
+    out[f"lp{i}_out"] = np.array([lp.ref_lower_pos(_p(g), g.size, float(x)) for x in xs], dtype=np.int32)
+out["lp_cases"] = np.array([len(grids)])
+
+# 101 chained iterations of main.cpp:536-581 with the reference's functions; tau by the oracle's read_tau (a5: the one
+# input here that is not a reference output -- stored, so the chain replays without it)
+for table in ("Reduced10", "Reduced100"):
+    tt = ol.read_rtab(os.path.join(ROOT, "tests", "golden", f"{table}Forcing.rtab"))
+    xs = np.ascontiguousarray(tt["xsec"])
+
+    def tau_of(Tl, v):
+        tau = np.zeros((tt["n_wvl"], 20))
+        olib.orc_read_tau(tt["n_tpert"], tt["n_species"], tt["n_wvl"], tt["n_p"], _p(tt["p_grid"]), _p(tt["t_ref"]),
+                          _p(tt["t_pert"]), _p(xs), 21, _p(ci["plevel"]), _p(np.ascontiguousarray(Tl)),
+                          _p(np.ascontiguousarray(v)), _p(tau))
+        ref.ref_cloud_into_tau(_p(tau), tt["n_wvl"])
+        return tau
+    Tl, Ts, vmr = ci["Tlayer"].copy(), 288.2, ci["vmr9"].copy()
+    tau = tau_of(Tl, vmr)
+    th, hist = np.zeros(20), []
+    for i in range(101):
+        ref.ref_convective_adjustment(_p(Tl), _p(th), _p(ci["conv"]))
+        if i != 0:
+            h2o = np.zeros(20)
+            ref.ref_water_vapor_feedback(_p(Tl), _p(ci["rel_hum"]), _p(ci["player"]), _p(h2o))
+            vmr[0] = h2o
+            tau = tau_of(Tl, vmr)
+        Ed, Eu, dE = ol.ref_radiative_transfer(ref, tau, tt["wvl"], tt["weight"], Tl, Ts, sol[6])
+        dt = ref.ref_calculate_timestep(50.0, _p(dE))
+        Ts = ref.ref_thermodynamics(_p(Tl), 50.0, _p(dE), dt, _p(ci["conv"]))
+        if i in (0, 1, 2, 10, 50, 100):
+            hist.append(np.concatenate([[i, dt, Ts], Tl, Ed, Eu, dE]))
+    out[f"chain_{table}"] = np.array(hist)
+
+path = os.path.join(ROOT, "tests", "golden", "ref_main_vectors.npz")
+np.savez_compressed(path, **out)
+print(path, os.path.getsize(path), "bytes,", len(out), "arrays")
