@@ -896,3 +896,24 @@ def test_lbl_fluxes_against_the_reference_pieces_wired_together(pkg, olib):
             f = g.get_fluxes()
         assert H.max_abs(f["E_down"][col], Ed) <= FLUX_TIGHT and H.max_abs(f["E_up"][col], Eu) <= FLUX_TIGHT, col
         assert H.max_abs(f["dE"][col], dE) <= FLUX_TIGHT, col
+
+
+@pytest.mark.parametrize("table", ["Reduced10", "Reduced100"])
+def test_gpu_against_the_committed_reference_vectors(pkg, golden, table):
+    """The HIP path against numbers the reference's own compiled functions produced (tests/golden/ref_main_vectors.npz,
+    tools/make_ref_vectors.py): time step, T_surface, Tlayer and the three flux profiles at iterations 0, 1, 2, 10, 50
+    and 100 of the loop main.cpp:531-583 for test.atm.  Needs neither the reference tree nor oracle/_ref nor the
+    oracle: never skips.  Contract 1e-6 W/m2 and 1e-6 K; asserted 1e-7 and 1e-8."""
+    v = np.load(os.path.join(golden, "ref_main_vectors.npz"))
+    inp = H.make_inputs(pkg, "repwvl", 1, table=table, perturb=False)
+    g = H.gpu_ensemble(pkg, inp)
+    done = 0
+    for row in v[f"chain_{table}"]:
+        i = int(row[0])
+        g.step(i + 1 - done)
+        done = i + 1
+        s, f = g.get_state(), g.get_fluxes()
+        assert abs(s["timestep"][0] - row[1]) <= 1e-9 * abs(row[1]), i
+        assert abs(s["T_surface"][0] - row[2]) <= 1e-8 and H.max_abs(s["Tlayer"][0], row[3:23]) <= 1e-8, i
+        assert H.max_abs(f["E_down"][0], row[23:44]) <= 1e-7 and H.max_abs(f["E_up"][0], row[44:65]) <= 1e-7, i
+        assert H.max_abs(f["dE"][0], row[65:85]) <= 1e-7, i
