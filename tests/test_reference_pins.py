@@ -432,7 +432,7 @@ def test_oracle_against_the_committed_reference_vectors(olib, golden):
     """The same pin WITHOUT the reference tree or oracle/_ref: tests/golden/ref_main_vectors.npz holds seeded inputs
     and the outputs of the reference's own compiled functions (tools/make_ref_vectors.py, run once where the
     reference tree is; data only).  The oracle must reproduce every number bit for bit: Planck, radiative_transfer on 40
-    random cases, time step + thermodynamics, adjustment + feedback, magnus, solar set-up, constants, LowerPos, and
+    random cases, time step + thermodynamics, adjustment + feedback, magnus, solar set-up, constants, LowerPos, 600 cplkavg.cpp values (all branches), and
     the state / fluxes at iterations 0, 1, 2, 10, 50, 100 of the 101-iteration chain for Reduced10 and Reduced100.
     Never skips."""
     v = np.load(os.path.join(golden, "ref_main_vectors.npz"))
@@ -463,6 +463,8 @@ def test_oracle_against_the_committed_reference_vectors(olib, golden):
     for i in range(int(v["lp_cases"][0])):
         g = np.ascontiguousarray(v[f"lp{i}_grid"])
         assert [olib.orc_lower_pos(_p(g), g.size, float(x)) for x in v[f"lp{i}_x"]] == v[f"lp{i}_out"].tolist(), i
+    for lo, hi, t, want in v["cplkavg"]:                       # a10: cplkavg.cpp, all three branches
+        assert olib.orc_cplkavg(float(lo), float(hi), float(t)) == want, (lo, hi, t)
     atm, _ = ol.atm_load(olib, os.path.join(golden, "test.atm"))
     ci = ol.column_init(olib, atm, 1.0, 1.0)
     for table in ("Reduced10", "Reduced100"):

@@ -130,6 +130,20 @@ for table in ("Reduced10", "Reduced100"):
             hist.append(np.concatenate([[i, dt, Ts], Tl, Ed, Eu, dE]))
     out[f"chain_{table}"] = np.array(hist)
 
+# a10: cplkavg.cpp as a whole translation unit (oracle/_ref/libref_cplkavg.so): close bounds (Simpson), wide bands at
+# thermal temperatures (exponential series), any temperature (power series included)
+import ctypes as C  # noqa: E402
+band = getattr(C.CDLL(os.path.join(ol.REF_DIR, "libref_cplkavg.so")), "_Z7cplkavgddd")
+band.restype, band.argtypes = C.c_double, [C.c_double] * 3
+rows = []
+for _ in range(600):
+    lo = float(np.exp(rng.uniform(np.log(300.0), np.log(2e5))))
+    kind = rng.integers(0, 3)
+    hi = lo * (1 + 10 ** rng.uniform(-6, -2.2)) if kind == 0 else lo * rng.uniform(1.011, 50.0)
+    t = float(rng.uniform(150.0, 350.0)) if kind < 2 else float(10 ** rng.uniform(0.5, 4))
+    rows.append([lo, hi, t, band(lo, hi, t)])
+out["cplkavg"] = np.array(rows)
+
 path = os.path.join(ROOT, "tests", "golden", "ref_main_vectors.npz")
 np.savez_compressed(path, **out)
 print(path, os.path.getsize(path), "bytes,", len(out), "arrays")
