@@ -1,18 +1,18 @@
 #!/usr/bin/env python3
-"""Writes tests/golden/ref_main_vectors.npz: inputs and OUTPUTS OF THE REFERENCE'S OWN COMPILED CODE
+"""TEST INFRASTRUCTURE.  Writes tests/golden/ref_main_vectors.npz: inputs and OUTPUTS OF THE REFERENCE'S OWN COMPILED CODE
 (oracle/_ref/libref_main.so = /root/reference/main.cpp:12-21,25-344 piped unedited into g++, oracle/Makefile) for
 the functions on the hot path, so that the oracle stays pinned in a checkout that has no reference tree (and no
 oracle/_ref): tests/test_reference_pins.py::test_oracle_against_the_committed_reference_vectors compares the oracle
 with these numbers bit for bit.  Data only: seeded inputs, the reference's outputs.  Needs the reference tree once:
 
-    make -C oracle && python tools/make_ref_vectors.py
+    make -C oracle && python tests/golden/make_ref_vectors.py
 """
 import os
 import sys
 
 import numpy as np
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 import oracle_lib as ol  # noqa: E402
 

@@ -901,7 +901,7 @@ def test_lbl_fluxes_against_the_reference_pieces_wired_together(pkg, olib):
 @pytest.mark.parametrize("table", ["Reduced10", "Reduced100"])
 def test_gpu_against_the_committed_reference_vectors(pkg, golden, table):
     """The HIP path against numbers the reference's own compiled functions produced (tests/golden/ref_main_vectors.npz,
-    tools/make_ref_vectors.py): time step, T_surface, Tlayer and the three flux profiles at iterations 0, 1, 2, 10, 50
+    tests/golden/make_ref_vectors.py): time step, T_surface, Tlayer and the three flux profiles at iterations 0, 1, 2, 10, 50
     and 100 of the loop main.cpp:531-583 for test.atm.  Needs neither the reference tree nor oracle/_ref nor the
     oracle: never skips.  Contract 1e-6 W/m2 and 1e-6 K; asserted 1e-7 and 1e-8."""
     v = np.load(os.path.join(golden, "ref_main_vectors.npz"))

@@ -430,7 +430,7 @@ def test_read_tau_reproduces_the_tables_own_nodes(olib, golden, table):
 
 def test_oracle_against_the_committed_reference_vectors(olib, golden):
     """The same pin WITHOUT the reference tree or oracle/_ref: tests/golden/ref_main_vectors.npz holds seeded inputs
-    and the outputs of the reference's own compiled functions (tools/make_ref_vectors.py, run once where the
+    and the outputs of the reference's own compiled functions (tests/golden/make_ref_vectors.py, run once where the
     reference tree is; data only).  The oracle must reproduce every number bit for bit: Planck, radiative_transfer on 40
     random cases, time step + thermodynamics, adjustment + feedback, magnus, solar set-up, constants, LowerPos, 600 cplkavg.cpp values (all branches), and
     the state / fluxes at iterations 0, 1, 2, 10, 50, 100 of the 101-iteration chain for Reduced10 and Reduced100.
