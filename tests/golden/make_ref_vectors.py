@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """TEST INFRASTRUCTURE.  Writes tests/golden/ref_main_vectors.npz: inputs and OUTPUTS OF THE REFERENCE'S OWN COMPILED CODE
-(oracle/_ref/libref_main.so = /root/reference/main.cpp:12-21,25-344 piped unedited into g++, oracle/Makefile) for
+(oracle/_ref/libref_main.so = /root/reference/main.cpp:12-21,25-344 piped unedited into g++; libref_readtau.so =
+the netCDF-free statements of repwvl_thermal.cpp:55-262 the same way; oracle/build_ref.sh) for
 the functions on the hot path, so that the oracle stays pinned in a checkout that has no reference tree (and no
 oracle/_ref): tests/test_reference_pins.py::test_oracle_against_the_committed_reference_vectors compares the oracle
 with these numbers bit for bit.  Data only: seeded inputs, the reference's outputs.  Needs the reference tree once:
@@ -19,8 +20,9 @@ import oracle_lib as ol  # noqa: E402
 _p = ol._p
 ref = ol.load_ref_main()
 lp = ol.load_ref_lowerpos()
-assert ref is not None and lp is not None, "build oracle/_ref first (make -C oracle, reference tree present)"
-olib = ol.load()  # only for the inputs that come from the atmosphere file and read_tau (a5, not a reference output)
+rt = ol.load_ref_readtau()
+assert None not in (ref, lp, rt), "build oracle/_ref first (make -C oracle, reference tree present)"
+olib = ol.load()  # only for the inputs that come from the atmosphere file (the loader / column set-up of main())
 rng = np.random.default_rng(20260104)
 out = {}
 
@@ -100,18 +102,33 @@ for i, g in enumerate(grids):
     out[f"lp{i}_out"] = np.array([lp.ref_lower_pos(_p(g), g.size, float(x)) for x in xs], dtype=np.int32)
 out["lp_cases"] = np.array([len(grids)])
 
-# 101 chained iterations of main.cpp:536-581 with the reference's functions; tau by the oracle's read_tau (a5: the one
-# input here that is not a reference output -- stored, so the chain replays without it)
+# a5: read_tau (repwvl_thermal.cpp:55-262 as compiled into libref_readtau.so), no cloud.  Per table: test.atm at 1x and
+# 2x CO2, then 10 perturbed columns: temperatures off by 5 / 40 / 150 K (the last leave t_ref + t_pert on both sides),
+# every gas scaled, CO / O2 / HNO3 / N2 present in half of them.  Inputs stored with the outputs.
+out["tau_plevel"] = ci["plevel"]
+for table in ("Reduced10", "Reduced20", "Reduced100"):
+    tt = ol.read_rtab(os.path.join(ROOT, "tests", "golden", f"{table}Forcing.rtab"))
+    Ts_, vs_, taus_ = [], [], []
+    for case in range(12):
+        if case < 2:
+            c2 = ol.column_init(olib, atm, float(case + 1), 1.0)
+            Tl, v = c2["Tlayer"].copy(), c2["vmr9"].copy()
+        else:
+            Tl = np.maximum(ci["Tlayer"] + rng.normal(size=20) * (5.0, 40.0, 150.0)[case % 3], 1.0)
+            v = ci["vmr9"] * rng.uniform(0.3, 3.0, (9, 1))
+            if case % 2:
+                v = v + 10 ** rng.uniform(-9, -3, (9, 20)) * (rng.random((9, 20)) < 0.7)
+        tau, _, _ = ol.ref_read_tau(rt, tt, ci["plevel"], Tl, v)
+        Ts_.append(Tl), vs_.append(v), taus_.append(tau)
+    out[f"tau_{table}_T"], out[f"tau_{table}_vmr"], out[f"tau_{table}_out"] = np.array(Ts_), np.array(vs_), np.array(taus_)
+
+# 101 chained iterations of main.cpp:536-581 with the reference's functions ALONE (read_tau included since round 4)
 for table in ("Reduced10", "Reduced100"):
     tt = ol.read_rtab(os.path.join(ROOT, "tests", "golden", f"{table}Forcing.rtab"))
-    xs = np.ascontiguousarray(tt["xsec"])
 
     def tau_of(Tl, v):
-        tau = np.zeros((tt["n_wvl"], 20))
-        olib.orc_read_tau(tt["n_tpert"], tt["n_species"], tt["n_wvl"], tt["n_p"], _p(tt["p_grid"]), _p(tt["t_ref"]),
-                          _p(tt["t_pert"]), _p(xs), 21, _p(ci["plevel"]), _p(np.ascontiguousarray(Tl)),
-                          _p(np.ascontiguousarray(v)), _p(tau))
-        ref.ref_cloud_into_tau(_p(tau), tt["n_wvl"])
+        tau, _, _ = ol.ref_read_tau(rt, tt, ci["plevel"], Tl, v)          # main.cpp:500 / :564
+        ref.ref_cloud_into_tau(_p(tau), tt["n_wvl"])                     # :504 / :568
         return tau
     Tl, Ts, vmr = ci["Tlayer"].copy(), 288.2, ci["vmr9"].copy()
     tau = tau_of(Tl, vmr)

@@ -299,6 +299,37 @@ def load_ref_lowerpos():
     return L
 
 
+def load_ref_readtau():
+    """oracle/_ref/libref_readtau.so = every netCDF-free statement of the reference's read_tau
+    (repwvl_thermal.cpp:55-111, 124-141, 153-168, 178-206, 210-262, unedited) + oracle/ref_readtau_shim.inc."""
+    p = os.path.join(REF_DIR, "libref_readtau.so")
+    if not os.path.exists(p):
+        return None
+    L = C.CDLL(p)
+    i = C.c_int
+    L.ref_read_tau.argtypes = [i, i, i, i, _dp, _dp, _dp, _dp, _dp, _dp, _dp, i, _dp, _dp, _dp, i, _dp, _dp, _dp]
+    L.ref_read_tau.restype = i
+    return L
+
+
+def ref_read_tau(L, t, plevel_hPa, T, vmr9, prop_at_lev=0):
+    """The reference's read_tau on a table dict of read_rtab().  vmr9: [9][nprop] top first (main.cpp's arrays).
+    Returns (tau[n_wvl][nlevel-1], wvl, weight) as the reference hands them to main()."""
+    pl = np.ascontiguousarray(plevel_hPa, dtype=np.float64)
+    T = np.ascontiguousarray(T, dtype=np.float64)
+    v = np.ascontiguousarray(vmr9, dtype=np.float64)
+    nlevel = pl.size
+    nprop = nlevel - 1 if prop_at_lev == 0 else nlevel
+    assert T.shape == (nprop,) and v.shape == (9, nprop)
+    xs = np.ascontiguousarray(t["xsec"])
+    tau, wvl, weight = np.zeros((t["n_wvl"], nlevel - 1)), np.zeros(t["n_wvl"]), np.zeros(t["n_wvl"])
+    n = L.ref_read_tau(t["n_tpert"], t["n_species"], t["n_wvl"], t["n_p"], _p(t["p_grid"]), _p(t["t_ref"]),
+                       _p(t["t_pert"]), _p(np.ascontiguousarray(t["vmrs_ref"])), _p(t["wvl"]), _p(t["weight"]), _p(xs),
+                       nlevel, _p(pl), _p(T), _p(v), prop_at_lev, _p(tau), _p(wvl), _p(weight))
+    assert n == t["n_wvl"]
+    return tau, wvl, weight
+
+
 def ref_mu(nangle=30):
     """main.cpp:355,481-482: dmu = 1/nangle, mu[i] = dmu/2 + dmu*i (the same IEEE operations)."""
     dmu = 1.0 / float(nangle)

@@ -917,3 +917,40 @@ def test_gpu_against_the_committed_reference_vectors(pkg, golden, table):
         assert abs(s["T_surface"][0] - row[2]) <= 1e-8 and H.max_abs(s["Tlayer"][0], row[3:23]) <= 1e-8, i
         assert H.max_abs(f["E_down"][0], row[23:44]) <= 1e-7 and H.max_abs(f["E_up"][0], row[44:65]) <= 1e-7, i
         assert H.max_abs(f["dE"][0], row[65:85]) <= 1e-7, i
+
+
+@pytest.mark.parametrize("table", ["Reduced10", "Reduced20", "Reduced100"])
+def test_gpu_tau_against_the_committed_reference_tau(pkg, golden, table):
+    """a5 on the GPU against the reference's own read_tau (repwvl_thermal.cpp:55-262 compiled as it stands,
+    oracle/_ref/libref_readtau.so; outputs committed as data in tests/golden/ref_main_vectors.npz): both optical-depth
+    getters -- rcm_get_tau (the reference's corner-difference form) and rcm_get_tau_production (what the kernels
+    form: pressure-interpolated table, folded weights, merged species, clamp to [-10, 1e7]) -- for 12 columns in ONE
+    ensemble: test.atm at 1x and 2x CO2 and ten perturbed profiles, four of which leave the table's temperature range
+    on both sides (read_tau extrapolates).  No cloud (read_tau has none).  <= 1e-12 relative to the largest
+    optical depth of the (wavelength, layer) row set, the contract of SURVEY.md 8(d); where extrapolated cross sections
+    cancel to ~0 the bound is relative to the layer's largest species term.  Needs neither the reference tree nor the
+    oracle: never skips."""
+    v = np.load(os.path.join(golden, "ref_main_vectors.npz"))
+    T, vmr, want = v[f"tau_{table}_T"], v[f"tau_{table}_vmr"], v[f"tau_{table}_out"]
+    n = T.shape[0]
+    inp = H.make_inputs(pkg, "repwvl", n, table=table, perturb=False)
+    c = inp["cols"]
+    assert c["plevel"].tolist() == v["tau_plevel"].tolist()
+    c["Tlayer0"][:], c["gas"][:] = T, vmr
+    g = H.gpu_ensemble(pkg, inp)
+    g.set_forcing(inp["solar"], cloud_layer=-1, cloud_tau=0.0)
+    t = inp["table"]
+    # scale of a layer's sum: sum_s |vmr_s| * max|xsec_s| * numDens -- what 1e-12 is relative to when terms cancel
+    pPa = c["plevel"] * 100.0
+    nd = (pPa[1:] - pPa[:-1]) * 6.02214076e23 / 0.0289647 / 9.80665
+    xmax = np.abs(t["xsec"]).max(axis=(0, 3))                       # [species][wvl]
+    for col in range(n):
+        scale = np.einsum("sl,sw->wl", np.abs(vmr[col]), xmax) * nd[None, :]
+        ref_form, prod = g.get_tau(col), g.get_tau_production(col)
+        clip = np.clip(want[col], -10.0, 1e7)
+        for got, w in ((ref_form, want[col]), (prod, clip)):
+            err = np.abs(got - w)
+            assert np.all(err <= 1e-12 * np.maximum(np.abs(w), 1e-3 * scale) + 1e-300), (table, col, float(err.max()))
+        if col < 2:                                                    # test.atm itself: plain relative
+            np.testing.assert_allclose(ref_form, want[col], rtol=1e-12, atol=0)
+            np.testing.assert_allclose(prod, want[col], rtol=1e-12, atol=0)

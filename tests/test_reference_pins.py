@@ -14,8 +14,11 @@ used by main() alone.  These tests assert  oracle/rcm_oracle.c == that compiled 
   a7  thermodynamics                               main.cpp:164-176
   a8  t_to_theta / sort / theta_to_t, magnus, water_vapor_feedback   main.cpp:123-139, 277-289, 536-540
   solar set-up                                     main.cpp:214-264
-  a5  LowerPos only (repwvl_thermal.cpp:19-45, libref_lowerpos.so); the interpolation statements of read_tau
-      read through netCDF::NcVar inside the loop and are NOT compiled: a5's arithmetic stays unpinned.
+  a5  LowerPos (repwvl_thermal.cpp:19-45, libref_lowerpos.so) and read_tau itself: libref_readtau.so = every
+      statement of repwvl_thermal.cpp:55-262 that names no netCDF type (:55-111, 124-141, 153-168, 178-206, 210-262:
+      unit conversion, reversals, numDens, brackets, the corner-difference interpolation :235-241, accumulation,
+      store order, transposition), compiled unedited; oracle/ref_readtau_shim.inc hands it the VALUES the skipped
+      getDim / getVar lines (:113-123, 143-149, 171-176, 208) would have delivered, from the same file's datasets.
 
 On the GPU box /root/reference does not exist; the prebuilt oracle/_ref/*.so travel with gpurun.  Without them
 (a fresh clone with no reference tree) the tests skip and say so.
@@ -37,6 +40,23 @@ def ref():
     if L is None:
         pytest.skip("oracle/_ref/libref_main.so not built (reference tree absent at build time)")
     return L
+
+
+@pytest.fixture(scope="module")
+def rtau():
+    L = ol.load_ref_readtau()
+    if L is None:
+        pytest.skip("oracle/_ref/libref_readtau.so not built (reference tree absent at build time)")
+    return L
+
+
+def _ref_tau(rtau, ref, t, ci, Tlayer, vmr9, cloud=True):
+    """The reference's read_tau (+ its cloud_into_tau): what main.cpp:500-504 / :564-568 produce."""
+    tau, wvl, weight = ol.ref_read_tau(rtau, t, ci["plevel"], Tlayer, vmr9)
+    assert wvl.tolist() == t["wvl"].tolist() and weight.tolist() == t["weight"].tolist()
+    if cloud:
+        ref.ref_cloud_into_tau(_p(tau), t["n_wvl"])
+    return tau
 
 
 def _column(olib, golden, co2=1.0):
@@ -230,11 +250,10 @@ def test_convective_adjustment_and_feedback_bit_identical(ref, olib, golden):
 
 
 @pytest.mark.parametrize("table,co2", [("Reduced10", 1.0), ("Reduced100", 1.0), ("Reduced20", 2.0)])
-def test_101_chained_steps_bit_identical(ref, olib, golden, table, co2):
-    """(iii): the loop body of main.cpp:531-583 driven HERE with the reference's compiled functions -- adjustment,
-    feedback, cloud, radiative_transfer, time step, thermodynamics -- and tau from orc_read_tau (a5, the row the
-    compiled reference cannot supply), against the oracle's own orc_step: state, fluxes and time step identical
-    after every one of the 101 iterations i = 0..100."""
+def test_101_chained_steps_bit_identical(ref, rtau, olib, golden, table, co2):
+    """(iii): the loop body of main.cpp:531-583 driven HERE with the reference's compiled functions ONLY -- adjustment,
+    feedback, read_tau, cloud, radiative_transfer, time step, thermodynamics -- against the oracle's own orc_step:
+    state, fluxes and time step identical after every one of the 101 iterations i = 0..100."""
     _, ci = _column(olib, golden, co2)
     t = ol.read_rtab(os.path.join(golden, f"{table}Forcing.rtab"))
     sol = np.zeros(7)
@@ -247,8 +266,7 @@ def test_101_chained_steps_bit_identical(ref, olib, golden, table, co2):
 
     T, Ts, vmr = ci["Tlayer"].copy(), 288.2, ci["vmr9"].copy()
     time_h = np.float32(0.0)
-    tau = _orc_tau(olib, t, ci, T, vmr, cloud=False)      # main.cpp:500: from the PRE-adjustment profile
-    ref.ref_cloud_into_tau(_p(tau), t["n_wvl"])           # :504
+    tau = _ref_tau(rtau, ref, t, ci, T, vmr)              # main.cpp:500-504: from the PRE-adjustment profile
     theta = np.zeros(20)
     for i in range(101):
         ref.ref_convective_adjustment(_p(T), _p(theta), _p(ci["conv"]))             # :536-540
@@ -256,8 +274,7 @@ def test_101_chained_steps_bit_identical(ref, olib, golden, table, co2):
             h2o = np.zeros(20)
             ref.ref_water_vapor_feedback(_p(T), _p(ci["rel_hum"]), _p(ci["player"]), _p(h2o))
             vmr[0] = h2o
-            tau = _orc_tau(olib, t, ci, T, vmr, cloud=False)
-            ref.ref_cloud_into_tau(_p(tau), t["n_wvl"])
+            tau = _ref_tau(rtau, ref, t, ci, T, vmr)                                  # :564-568
         Ed, Eu, dE = ol.ref_radiative_transfer(ref, tau, t["wvl"], t["weight"], T, Ts, sol[6])   # :574
         dt = ref.ref_calculate_timestep(50.0, _p(dE))                                 # :576
         Ts = ref.ref_thermodynamics(_p(T), 50.0, _p(dE), dt, _p(ci["conv"]))          # :578
@@ -300,9 +317,62 @@ def test_lower_pos_bit_identical(olib, golden):
     assert n > 4000
 
 
+@pytest.mark.parametrize("table", ["Reduced10", "Reduced20", "Reduced100"])
+def test_read_tau_bit_identical_to_the_compiled_reference(rtau, olib, golden, table):
+    """a5: orc_read_tau == the reference's read_tau statements compiled as they stand (libref_readtau.so), BIT FOR BIT:
+    test.atm at 1x and 2x CO2; profiles perturbed by 5 / 40 / 150 K (temperatures leave the table on both sides:
+    delT < 0 and > 1); every species present incl. the ones main.cpp zeroes; random positive and zero mixing ratios;
+    random monotone pressure grids with 5..40 levels, among them surface pressures above the table's largest
+    (LowerPos returns the last bracket, delP ~ -1e8) and a top at 0 hPa; the wavelength and weight vectors handed
+    back are the table's.  prop_at_Lev = 0 as main.cpp:495 fixes it (the level variant is not on the path and the
+    oracle does not restate it)."""
+    atm, _ = ol.atm_load(olib, os.path.join(golden, "test.atm"))
+    t = ol.read_rtab(os.path.join(golden, f"{table}Forcing.rtab"))
+    xs = np.ascontiguousarray(t["xsec"])
+    rng = np.random.default_rng(45)
+
+    def both(plevel, T, vmr):
+        plevel, T, vmr = (np.ascontiguousarray(a, dtype=np.float64) for a in (plevel, T, vmr))
+        want, wvl, weight = ol.ref_read_tau(rtau, t, plevel, T, vmr)
+        assert wvl.tolist() == t["wvl"].tolist() and weight.tolist() == t["weight"].tolist()
+        got = np.zeros_like(want)
+        olib.orc_read_tau(t["n_tpert"], t["n_species"], t["n_wvl"], t["n_p"], _p(t["p_grid"]), _p(t["t_ref"]),
+                          _p(t["t_pert"]), _p(xs), plevel.size, _p(plevel), _p(T), _p(vmr), _p(got))
+        assert np.isfinite(want).all()
+        assert got.tolist() == want.tolist()
+        return want
+
+    n = 0
+    for co2 in (1.0, 2.0, 0.5, 4.0):
+        ci = ol.column_init(olib, atm, co2, 1.0)
+        tau = both(ci["plevel"], ci["Tlayer"], ci["vmr9"])
+        n += 1
+        if table == "Reduced100" and co2 == 1.0:                      # SURVEY.md 8(c) samples
+            assert abs(tau[0, 0] - 9.94215e-05) < 1e-10 and abs(tau[99, 19] - 113.779) < 1e-3
+    ci = ol.column_init(olib, atm, 1.0, 1.0)
+    for case in range(60):
+        T = ci["Tlayer"] + rng.normal(size=20) * (5.0, 40.0, 150.0)[case % 3]
+        vmr = ci["vmr9"] * rng.uniform(0.3, 3.0, (9, 1))
+        if case % 2:
+            vmr = vmr + 10 ** rng.uniform(-9, -2, (9, 20)) * (rng.random((9, 20)) < 0.7)   # CO, O2, HNO3, N2 too
+        both(ci["plevel"], np.maximum(T, 1.0), vmr)
+        n += 1
+    for case in range(60):                                             # other grids
+        nlev = int(rng.integers(5, 41))
+        top = 0.0 if case % 3 == 0 else float(10 ** rng.uniform(-4, 1))
+        sfc = float(rng.uniform(600.0, 1099.0)) if case % 4 else float(rng.uniform(1100.5, 1300.0))  # table ends at 1100 hPa
+        pl = np.sort(np.concatenate([[top, sfc], rng.uniform(top, sfc, nlev - 2)]))
+        if np.any(np.diff(pl) <= 0):
+            continue
+        T = rng.uniform(150.0, 330.0, nlev - 1)
+        vmr = 10 ** rng.uniform(-8, -1.5, (9, nlev - 1)) * (rng.random((9, 1)) < 0.8)
+        both(pl, T, vmr)
+        n += 1
+    assert n > 100
+
+
 def test_read_tau_against_an_independent_array_statement(olib, golden):
-    """a5's interpolation arithmetic cannot be pinned by a compiled reference (module docstring).  Second opinion, so
-    that the one unpinned row does not rest on a single restatement: the same rules written again, array-wise and
+    """Second opinion beside the compiled pin above (kept from the rounds in which a5 had none): the same rules written again, array-wise and
     from the text of repwvl_thermal.cpp:197-248 (not from oracle/rcm_oracle.c) -- brackets by a vectorised sign-change
     search, the four corners gathered with fancy indexing, the corner-difference form, species sum, number density --
     against orc_read_tau on test.atm x Reduced10/20/100 and on perturbed profiles that leave the table on both sides.
@@ -432,9 +502,11 @@ def test_oracle_against_the_committed_reference_vectors(olib, golden):
     """The same pin WITHOUT the reference tree or oracle/_ref: tests/golden/ref_main_vectors.npz holds seeded inputs
     and the outputs of the reference's own compiled functions (tests/golden/make_ref_vectors.py, run once where the
     reference tree is; data only).  The oracle must reproduce every number bit for bit: Planck, radiative_transfer on 40
-    random cases, time step + thermodynamics, adjustment + feedback, magnus, solar set-up, constants, LowerPos, 600 cplkavg.cpp values (all branches), and
-    the state / fluxes at iterations 0, 1, 2, 10, 50, 100 of the 101-iteration chain for Reduced10 and Reduced100.
-    Never skips."""
+    random cases, time step + thermodynamics, adjustment + feedback, magnus, solar set-up, constants, LowerPos, 600
+    cplkavg.cpp values (all branches), read_tau's optical depths for 12 columns x Reduced10/20/100 (a5; test.atm at
+    1x / 2x CO2 and perturbed profiles that leave the table on both sides), and the state / fluxes at iterations 0, 1,
+    2, 10, 50, 100 of the 101-iteration chain for Reduced10 and Reduced100 (every function of the chain, read_tau
+    included, was the reference's when the vectors were made).  Never skips."""
     v = np.load(os.path.join(golden, "ref_main_vectors.npz"))
     wvl, wgt, T = v["planck_in"]
     assert [olib.orc_planck_mono(float(a), float(b), float(c)) for a, b, c in zip(wvl, wgt, T)] == v["planck_out"].tolist()
@@ -467,6 +539,11 @@ def test_oracle_against_the_committed_reference_vectors(olib, golden):
         assert olib.orc_cplkavg(float(lo), float(hi), float(t)) == want, (lo, hi, t)
     atm, _ = ol.atm_load(olib, os.path.join(golden, "test.atm"))
     ci = ol.column_init(olib, atm, 1.0, 1.0)
+    assert ci["plevel"].tolist() == v["tau_plevel"].tolist()
+    for table in ("Reduced10", "Reduced20", "Reduced100"):     # a5: read_tau
+        t = ol.read_rtab(os.path.join(golden, f"{table}Forcing.rtab"))
+        for Tl, vm, want in zip(v[f"tau_{table}_T"], v[f"tau_{table}_vmr"], v[f"tau_{table}_out"]):
+            assert _orc_tau(olib, t, ci, Tl, vm, cloud=False).tolist() == want.tolist(), table
     for table in ("Reduced10", "Reduced100"):
         e = ol.OracleEnsemble(olib, 1)
         e.set_grid(ci["plevel"])
