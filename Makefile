@@ -24,9 +24,9 @@ examples: examples/abi_minimal
 examples/abi_minimal: examples/abi_minimal.cpp $(LIB) include/rcm.h
 	g++ -O2 -std=c++17 -Iinclude -o $@ $< -L$(PKG) -lrcm_hip -Wl,-rpath,'$$ORIGIN/../$(PKG)'
 
-$(LIB): $(CSRC)/rcm_capi.hip $(CSRC)/rcm_host.cpp $(CSRC)/rcm_nc.cpp $(HDRS)
+$(LIB): $(CSRC)/rcm_capi.hip $(CSRC)/rcm_host.cpp $(CSRC)/rcm_nc.cpp $(HDRS) $(CSRC)/rcm_exports.map
 	$(HIPCC) -O3 -std=c++17 -fPIC --offload-arch=gfx950 -Iinclude -I$(CSRC) -Wall -Wno-unused-function -shared -o $@ \
-	  $(CSRC)/rcm_capi.hip $(CSRC)/rcm_host.cpp $(CSRC)/rcm_nc.cpp
+	  -Wl,--version-script=$(CSRC)/rcm_exports.map $(CSRC)/rcm_capi.hip $(CSRC)/rcm_host.cpp $(CSRC)/rcm_nc.cpp
 
 $(MAIN): $(CSRC)/rcm_main.cpp $(LIB) include/rcm.h
 	g++ -O2 -std=c++17 -Iinclude -o $@ $(CSRC)/rcm_main.cpp -L$(PKG) -lrcm_hip -Wl,-rpath,'$$ORIGIN' $(RCCL_FLAGS)

@@ -271,7 +271,7 @@ def main():
     coll_dev = "cuda" if args.backend == "nccl" else "cpu"
 
     import our_first_climate_model_amd as pkg
-    from our_first_climate_model_amd.distributed import gather_state, shard_bounds
+    from our_first_climate_model_amd.distributed import gather_state, shard_bounds, shard_ensemble
 
     ncol_total = args.ncol * (world if args.scaling == "weak" else 1)
     lo, hi = shard_bounds(ncol_total, rank, world)
@@ -294,7 +294,7 @@ def main():
         inp = dict(mode="repwvl", ncol=ncol_local, cols=cols, solar=pkg.default_solar()["solar_irr"], table=table)
         nspec = table["n_wvl"]
     stream = torch.cuda.current_stream().cuda_stream
-    ens = pkg.configure(pkg.Ensemble(ncol_local, device=dev_index, stream=stream), inp)
+    ens = shard_ensemble(pkg, inp, device=dev_index, stream=stream)  # no handle on a rank without columns
     if args.chunks:
         ens.set_spectral_chunks(args.chunks)
     packed = torch.empty((ncol_local, 21), dtype=torch.float64, device="cuda")

@@ -49,7 +49,7 @@ def main():
     import torch
     import torch.distributed as dist
     import our_first_climate_model_amd as rcm
-    from our_first_climate_model_amd.distributed import gather_state, run_to_equilibrium, shard_bounds
+    from our_first_climate_model_amd.distributed import gather_state, run_to_equilibrium, shard_bounds, shard_ensemble
 
     rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
     shard = None
@@ -74,7 +74,7 @@ def main():
         cols["T_surface0"][a.nan_column - lo] = float("nan")
     wvl, tabs = rcm.synth_lbl_tables(a.nodes, plevel=cols["plevel"])
     inp = dict(mode="lbl", ncol=hi - lo, cols=cols, solar=rcm.default_solar()["solar_irr"], wvl=wvl, tabs=tabs)
-    ens = rcm.configure(rcm.Ensemble(hi - lo, device=dev, stream=torch.cuda.current_stream().cuda_stream), inp)
+    ens = shard_ensemble(rcm, inp, device=dev, stream=torch.cuda.current_stream().cuda_stream)  # empty block: no handle
 
     torch.cuda.synchronize()
     t0 = time.perf_counter()

@@ -28,9 +28,10 @@ VARIANTS_LIB = os.path.join(ROOT, "tests", "_variants", "librcm_hip_variants.so"
 def _sources():
     srcs = [os.path.join(CSRC, s) for s in SOURCES]
     deps = srcs + [os.path.join(CSRC, h) for h in HEADERS] + [os.path.join(ROOT, "include", "rcm.h")]
+    exports = os.path.join(CSRC, "rcm_exports.map")  # the C ABI of include/rcm.h is ALL the library exports
     common = ["-O3", "-std=c++17", "-fPIC", "--offload-arch=gfx950", "-I" + os.path.join(ROOT, "include"),
-              "-I" + CSRC, "-Wall", "-Wno-unused-function"]
-    return srcs, deps, common
+              "-I" + CSRC, "-Wall", "-Wno-unused-function", "-Wl,--version-script=" + exports]
+    return srcs, deps + [exports], common
 
 
 def build_variants(force=False):

@@ -524,15 +524,17 @@ int rcm_create(int ncol, int nlayer, int nangle, int device, void *stream, rcm_e
   if (const char *v = std::getenv("RCM_PAIR")) h->pair = std::atoi(v) ? 1 : 0;
   if (const char *v = std::getenv("RCM_FLAT")) h->flat = std::atoi(v) ? 1 : 0;
 #endif
-  auto bail = [&](int rc) {
-    rcm_destroy(h);
-    return rc;
-  };
-  if (int rc = use_device(h)) return bail(rc);
+  struct Guard {  // a half-built handle (and its device buffers) goes away on every way out, an exception included
+    rcm_ensemble *h;
+    ~Guard() {
+      if (h) rcm_destroy(h);
+    }
+  } guard{h};
+  if (int rc = use_device(h)) return rc;
   if (stream) {
     h->stream = (hipStream_t)stream;
   } else {
-    if (hipStreamCreate(&h->stream) != hipSuccess) return bail(fail(RCM_ERR_HIP, "hipStreamCreate failed"));
+    if (hipStreamCreate(&h->stream) != hipSuccess) return fail(RCM_ERR_HIP, "hipStreamCreate failed");
     h->own_stream = true;
   }
   Dev &d = h->d;
@@ -563,7 +565,7 @@ int rcm_create(int ncol, int nlayer, int nangle, int device, void *stream, rcm_e
   rc = rc ? rc : dev_alloc(h, &h->d_ip, (size_t)NL);
   rc = rc ? rc : dev_alloc(h, &h->d_delP, (size_t)NL);
   rc = rc ? rc : dev_alloc(h, &h->d_numDens, (size_t)NL);
-  if (rc) return bail(rc);
+  if (rc) return rc;
   d.ip = h->d_ip, d.delP = h->d_delP, d.numDens = h->d_numDens;
   // angles: mu_i = dmu/2 + dmu*i (main.cpp:356,482); weight 2*pi*mu*dmu (main.cpp:302,308,313)
   std::vector<double> ang(2 * (size_t)nangle + 1, 0.0);
@@ -599,7 +601,7 @@ int rcm_create(int ncol, int nlayer, int nangle, int device, void *stream, rcm_e
     for (int n = N; n >= 1; n -= 2)
       if (is_root(n) && !used[n]) push(-ang[(n - 1) >> 1] * log2e, n, 0), ++d.nsched;
   }
-  if ((rc = dev_upload(h, (double **)&d.ang, ang.data(), ang.size()))) return bail(rc);
+  if ((rc = dev_upload(h, (double **)&d.ang, ang.data(), ang.size()))) return rc;
   hipError_t me = hipMemsetAsync(d.time_h, 0, ncol * sizeof(float), h->stream);
   if (me == hipSuccess) me = hipMemsetAsync(d.dt, 0, ncol * sizeof(double), h->stream);
   if (me == hipSuccess) me = hipMemsetAsync(d.E_down, 0, nE * sizeof(double), h->stream);
@@ -608,10 +610,11 @@ int rcm_create(int ncol, int nlayer, int nangle, int device, void *stream, rcm_e
   if (me == hipSuccess) me = hipMemsetAsync(d.resid, 0, ncol * sizeof(double), h->stream);
   if (me == hipSuccess) me = hipMemsetAsync(d.Tprev, 0, nT * sizeof(double), h->stream);
   if (me == hipSuccess) me = hipStreamSynchronize(h->stream);
-  if (me != hipSuccess) return bail(fail(RCM_ERR_HIP, std::string("rcm_create: ") + hipGetErrorString(me)));
+  if (me != hipSuccess) return fail(RCM_ERR_HIP, std::string("rcm_create: ") + hipGetErrorString(me));
   // the reference's compiled-in forcing until the caller says otherwise: cloud in layer 17 with
   // tau_s/2 = 1.0 (main.cpp:86,92,267), solar heating 0
-  if ((rc = rcm_set_forcing(h, 0.0, 17, 2.0 / 2.0))) return bail(rc);
+  if ((rc = rcm_set_forcing(h, 0.0, 17, 2.0 / 2.0))) return rc;
+  guard.h = nullptr;
   *out = h;
   return RCM_OK;
 } RCM_ABI_CATCH
@@ -901,7 +904,10 @@ int rcm_step(rcm_ensemble *h, int nsteps) try {
     return fail(RCM_ERR_STATE, "rcm_step: grid, spectral tables and columns must be set first");
   if (int rc = use_device(h)) return rc;
 #ifdef RCM_WITH_VARIANTS
-  if (const int lpc = choose_lpc(h)) return launch_fused_steps(h, lpc, nsteps);
+  if (const int lpc = choose_lpc(h)) {
+    h->img_valid = false;  // k_step_repwvl keeps its images in LDS: d.img is stale after it
+    return launch_fused_steps(h, lpc, nsteps);
+  }
 #endif
   if (!h->d.partial)
     if (int rc = ensure_partials(h)) return rc;
@@ -950,6 +956,7 @@ int rcm_dbg_eval(int fn, int n, const double *a, const double *b, const double *
 int rcm_set_step_fusion(rcm_ensemble *h, int mode) try {
   if (!h || mode < -1 || mode > 1) return fail(RCM_ERR_ARG, "rcm_set_step_fusion: mode must be -1 (automatic), 0 or 1");
   h->fusion = mode;
+  h->img_valid = false;
   return RCM_OK;
 } RCM_ABI_CATCH
 
@@ -1136,7 +1143,7 @@ int rcm_checkpoint_save(rcm_ensemble *h, const char *path) try {
   if (!h || !path) return fail(RCM_ERR_ARG, "rcm_checkpoint_save: bad argument");
   if (!h->have_columns) return fail(RCM_ERR_STATE, "rcm_checkpoint_save: columns not set");
   if (int rc = use_device(h)) return rc;
-  FILE *f = std::fopen(path, "wb");
+  rcm::File f(std::fopen(path, "wb"));  // closed on every way out
   if (!f) return fail(RCM_ERR_IO, std::string("rcm_checkpoint_save: cannot open ") + path);
   const long long hdr[5] = {h->ncol, NL, h->d.ngas, h->mode, h->step_index};
   bool ok = std::fwrite("RCMCKPT1", 1, 8, f) == 8 && std::fwrite(hdr, sizeof(long long), 5, f) == 5;
@@ -1145,13 +1152,11 @@ int rcm_checkpoint_save(rcm_ensemble *h, const char *path) try {
     buf.resize(fld.bytes);
     hipError_t e = hipMemcpyAsync(buf.data(), fld.dev, fld.bytes, hipMemcpyDeviceToHost, h->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
-    if (e != hipSuccess) {
-      std::fclose(f);
+    if (e != hipSuccess)
       return fail(RCM_ERR_HIP, std::string("rcm_checkpoint_save: ") + hipGetErrorString(e));
-    }
     ok = ok && std::fwrite(buf.data(), 1, fld.bytes, f) == fld.bytes;
   }
-  ok = (std::fclose(f) == 0) && ok;
+  ok = (f.close() == 0) && ok;
   return ok ? RCM_OK : fail(RCM_ERR_IO, std::string("rcm_checkpoint_save: write failed: ") + path);
 } RCM_ABI_CATCH
 
@@ -1160,44 +1165,31 @@ int rcm_checkpoint_load(rcm_ensemble *h, const char *path) try {
   if (h->mode == rcm::MODE_NONE || !h->have_grid)
     return fail(RCM_ERR_STATE, "rcm_checkpoint_load: set the grid and the spectral tables first");
   if (int rc = use_device(h)) return rc;
-  FILE *f = std::fopen(path, "rb");
+  rcm::File f(std::fopen(path, "rb"));  // closed on every way out
   if (!f) return fail(RCM_ERR_IO, std::string("rcm_checkpoint_load: cannot open ") + path);
   char magic[8];
   long long hdr[5];
   if (std::fread(magic, 1, 8, f) != 8 || std::memcmp(magic, "RCMCKPT1", 8) != 0 ||
-      std::fread(hdr, sizeof(long long), 5, f) != 5) {
-    std::fclose(f);
+      std::fread(hdr, sizeof(long long), 5, f) != 5)
     return fail(RCM_ERR_FORMAT, std::string("rcm_checkpoint_load: not an RCMCKPT1 file: ") + path);
-  }
-  if (hdr[0] != h->ncol || hdr[1] != NL || hdr[2] != h->d.ngas || hdr[3] != h->mode || hdr[4] < 0) {
-    std::fclose(f);
+  if (hdr[0] != h->ncol || hdr[1] != NL || hdr[2] != h->d.ngas || hdr[3] != h->mode || hdr[4] < 0)
     return fail(RCM_ERR_ARG, "rcm_checkpoint_load: checkpoint does not match this ensemble (ncol/nlayer/species/mode)");
-  }
   if (!h->d.gas)
-    if (int rc = dev_alloc(h, &h->d.gas, (size_t)h->ncol * NL * h->d.ngas)) {
-      std::fclose(f);
+    if (int rc = dev_alloc(h, &h->d.gas, (size_t)h->ncol * NL * h->d.ngas))
       return rc;
-    }
   std::vector<char> buf;
   for (const auto &fld : ckpt_fields(h)) {
     buf.resize(fld.bytes);
-    if (std::fread(buf.data(), 1, fld.bytes, f) != fld.bytes) {
-      std::fclose(f);
+    if (std::fread(buf.data(), 1, fld.bytes, f) != fld.bytes)
       return fail(RCM_ERR_FORMAT, std::string("rcm_checkpoint_load: truncated file: ") + path);
-    }
     hipError_t e = hipMemcpyAsync(fld.dev, buf.data(), fld.bytes, hipMemcpyHostToDevice, h->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
-    if (e != hipSuccess) {
-      std::fclose(f);
+    if (e != hipSuccess)
       return fail(RCM_ERR_HIP, std::string("rcm_checkpoint_load: ") + hipGetErrorString(e));
-    }
     if (fld.dev == (void *)h->d.gas && h->mode == rcm::MODE_REPWVL)  // the species pattern of the run that saved it
-      if (int rc = classify_species(h, reinterpret_cast<const double *>(buf.data()))) {
-        std::fclose(f);
+      if (int rc = classify_species(h, reinterpret_cast<const double *>(buf.data())))
         return rc;
-      }
   }
-  std::fclose(f);
   h->step_index = hdr[4];
   h->have_columns = true;
   h->img_valid = false;  // (classify_species cleared the images; the next step or the optical-depth getter rebuilds them)

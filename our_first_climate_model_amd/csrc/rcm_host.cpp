@@ -14,6 +14,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <fstream>
+#include <memory>
 #include <sstream>
 #include <string>
 #include <vector>
@@ -222,6 +223,8 @@ int rcm_ascii_file2xy2D(const char *path, int *nx, int *ny, double **x, double *
   return 0;
 } catch (const std::bad_alloc &) {
   return fail(-2, "no memory");  // ASCII_NO_MEMORY, the reference's own code (no exception may cross the C ABI)
+} catch (const std::exception &) {
+  return fail(-2, "no memory");  // std::length_error of the value vector: the same condition under another name
 }
 
 // Bytes left in f behind the current position (the readers below size their allocations from header fields of an
@@ -239,39 +242,29 @@ static long long bytes_left(FILE *f) {
 // ---------------------------------------------------------------------------------------------
 int rcm_rtab_load(const char *path, long long dims[4], double **blob) try {
   if (!path || !dims || !blob) return fail(RCM_ERR_ARG, "rcm_rtab_load: bad argument");
-  FILE *f = std::fopen(path, "rb");
+  rcm::File f(std::fopen(path, "rb"));  // closed on every way out, a throwing error message included
   if (!f) return fail(RCM_ERR_IO, std::string("rcm_rtab_load: cannot open ") + path);
   char magic[8];
   long long d[4];
   if (std::fread(magic, 1, 8, f) == 8 && std::memcmp(magic, "\x89HDF\r\n\x1a\n", 8) == 0) {
-    std::fclose(f);  // a Reduced*Forcing.nc itself (NetCDF-4 = HDF5), as the reference opens it
+    f.close();  // a Reduced*Forcing.nc itself (NetCDF-4 = HDF5), as the reference opens it
     return rcm::nc_table_load(path, dims, blob);
   }
   std::rewind(f);
   if (std::fread(magic, 1, 8, f) != 8 || std::memcmp(magic, "RWVLTAB1", 8) != 0 ||
       std::fread(d, sizeof(long long), 4, f) != 4 || d[0] < 2 || d[1] < 1 || d[2] < 1 || d[3] < 2 ||
-      d[0] > 4096 || d[1] > 4096 || d[2] > (1 << 24) || d[3] > 4096) {
-    std::fclose(f);
+      d[0] > 4096 || d[1] > 4096 || d[2] > (1 << 24) || d[3] > 4096)
     return fail(RCM_ERR_FORMAT, std::string("rcm_rtab_load: not an RWVLTAB1 blob: ") + path);
-  }
   const size_t nt = d[0], ns = d[1], nw = d[2], np = d[3];
   const size_t n = np + np + nt + ns * np + nw + nw + nt * ns * nw * np;  // (< 2^61 with the limits above: no wrap)
   const long long have = bytes_left(f);
-  if (have < 0 || (unsigned long long)have / sizeof(double) < n) {
-    std::fclose(f);
+  if (have < 0 || (unsigned long long)have / sizeof(double) < n)
     return fail(RCM_ERR_FORMAT, std::string("rcm_rtab_load: truncated blob: ") + path);
-  }
-  double *b = (double *)std::malloc(n * sizeof(double));
-  if (!b) {
-    std::fclose(f);
-    return fail(RCM_ERR_NOMEM, "rcm_rtab_load: out of memory");
-  }
-  if (std::fread(b, sizeof(double), n, f) != n) {
-    std::free(b);
-    std::fclose(f);
+  std::unique_ptr<double, decltype(&std::free)> buf((double *)std::malloc(n * sizeof(double)), &std::free);
+  if (!buf) return fail(RCM_ERR_NOMEM, "rcm_rtab_load: out of memory");
+  if (std::fread(buf.get(), sizeof(double), n, f) != n)
     return fail(RCM_ERR_FORMAT, std::string("rcm_rtab_load: truncated blob: ") + path);
-  }
-  std::fclose(f);
+  double *b = buf.release();
   for (int i = 0; i < 4; ++i) dims[i] = d[i];
   *blob = b;
   return RCM_OK;
@@ -286,7 +279,7 @@ int rcm_lbl_cache_write(const char *path, int n_nodes, int nlayer, const double 
   if (!path || !wvl || !tabs || n_nodes < 2 || nlayer < 1) return fail(RCM_ERR_ARG, "rcm_lbl_cache_write: bad argument");
   for (int s = 0; s < RCM_NSPEC_LBL; ++s)
     if (!tabs[s]) return fail(RCM_ERR_ARG, "rcm_lbl_cache_write: NULL table");
-  FILE *f = std::fopen(path, "wb");
+  rcm::File f(std::fopen(path, "wb"));
   if (!f) return fail(RCM_ERR_IO, std::string("rcm_lbl_cache_write: cannot open ") + path);
   const long long dims[2] = {n_nodes, nlayer};
   bool ok = std::fwrite("LBLTAB1", 1, 8, f) == 8 && std::fwrite(dims, sizeof(long long), 2, f) == 2 &&
@@ -297,49 +290,40 @@ int rcm_lbl_cache_write(const char *path, int n_nodes, int nlayer, const double 
       for (int b = 0; b < n_nodes; ++b) row[b] = tabs[s][(size_t)b * nlayer + l];
       ok = std::fwrite(row.data(), sizeof(double), (size_t)n_nodes, f) == (size_t)n_nodes;
     }
-  ok = (std::fclose(f) == 0) && ok;
+  ok = (f.close() == 0) && ok;
   return ok ? RCM_OK : fail(RCM_ERR_IO, std::string("rcm_lbl_cache_write: write failed: ") + path);
 } RCM_ABI_CATCH
 
 int rcm_lbl_cache_read(const char *path, int *n_nodes, int *nlayer, double **wvl, double **tabs) try {
   if (!path || !n_nodes || !nlayer || !wvl || !tabs) return fail(RCM_ERR_ARG, "rcm_lbl_cache_read: bad argument");
-  FILE *f = std::fopen(path, "rb");
+  rcm::File f(std::fopen(path, "rb"));
   if (!f) return fail(RCM_ERR_IO, std::string("rcm_lbl_cache_read: cannot open ") + path);
   char magic[8];
   long long dims[2];
   if (std::fread(magic, 1, 8, f) != 8 || std::memcmp(magic, "LBLTAB1", 8) != 0 ||
       std::fread(dims, sizeof(long long), 2, f) != 2 || dims[0] < 2 || dims[0] > (1LL << 28) || dims[1] < 1 ||
-      dims[1] > 4096) {
-    std::fclose(f);
+      dims[1] > 4096)
     return fail(RCM_ERR_FORMAT, std::string("rcm_lbl_cache_read: not an LBLTAB1 file: ") + path);
-  }
   const size_t n = (size_t)dims[0], nl = (size_t)dims[1];
   const long long have = bytes_left(f);
-  if (have < 0 || (unsigned long long)have / sizeof(double) < n + (size_t)RCM_NSPEC_LBL * n * nl) {
-    std::fclose(f);
+  if (have < 0 || (unsigned long long)have / sizeof(double) < n + (size_t)RCM_NSPEC_LBL * n * nl)
     return fail(RCM_ERR_FORMAT, std::string("rcm_lbl_cache_read: truncated file: ") + path);
-  }
-  double *w = (double *)std::malloc(n * sizeof(double));
-  double *t = (double *)std::malloc((size_t)RCM_NSPEC_LBL * n * nl * sizeof(double));
-  double *row = (double *)std::malloc(n * sizeof(double));  // (no exception may cross the C ABI: malloc, not std::vector)
-  bool ok = w && t && row && std::fread(w, sizeof(double), n, f) == n;
+  using Buf = std::unique_ptr<double, decltype(&std::free)>;  // freed on every way out; released to the caller at the end
+  Buf w((double *)std::malloc(n * sizeof(double)), &std::free);
+  Buf t((double *)std::malloc((size_t)RCM_NSPEC_LBL * n * nl * sizeof(double)), &std::free);
+  Buf row((double *)std::malloc(n * sizeof(double)), &std::free);
+  if (!w || !t || !row) return fail(RCM_ERR_NOMEM, std::string("rcm_lbl_cache_read: out of memory: ") + path);
+  bool ok = std::fread(w.get(), sizeof(double), n, f) == n;
   for (size_t s = 0; ok && s < RCM_NSPEC_LBL; ++s)
     for (size_t l = 0; ok && l < nl; ++l) {
-      ok = std::fread(row, sizeof(double), n, f) == n;
-      for (size_t b = 0; ok && b < n; ++b) t[(s * n + b) * nl + l] = row[b];
+      ok = std::fread(row.get(), sizeof(double), n, f) == n;
+      for (size_t b = 0; ok && b < n; ++b) t.get()[(s * n + b) * nl + l] = row.get()[b];
     }
-  std::fclose(f);
-  const bool nomem = !w || !t || !row;
-  std::free(row);
-  if (!ok) {
-    std::free(w);
-    std::free(t);
-    return fail(nomem ? RCM_ERR_NOMEM : RCM_ERR_FORMAT, std::string("rcm_lbl_cache_read: truncated or out of memory: ") + path);
-  }
+  if (!ok) return fail(RCM_ERR_FORMAT, std::string("rcm_lbl_cache_read: truncated file: ") + path);
   *n_nodes = (int)n;
   *nlayer = (int)nl;
-  *wvl = w;
-  *tabs = t;
+  *wvl = w.release();
+  *tabs = t.release();
   return RCM_OK;
 } RCM_ABI_CATCH
 

@@ -12,6 +12,48 @@ def shard_bounds(ncol_total, rank, world):
     return lo, min(lo + per, ncol_total)
 
 
+class EmptyShard:
+    """The rank that holds NO columns (9 columns on 8 ranks: ranks 5..7).  rcm_create refuses an ensemble of zero
+    columns, so such a rank creates no handle and touches no kernel -- but it must still join every collective
+    (the residual all-reduce of run_to_equilibrium, the final all-gather, the barriers), or the other ranks hang.
+    Same surface as Ensemble as far as the multi-rank drivers use it; every call is a no-op."""
+    ncol = 0
+
+    def step(self, n=1):
+        pass
+
+    def get_residual(self):
+        return np.zeros(0)
+
+    def pack_state(self, dev_ptr):
+        pass
+
+    def sync(self):
+        pass
+
+    def set_rt_timing(self, on):
+        pass
+
+    def get_rt_timing(self):
+        return 0.0, 0
+
+    def set_spectral_chunks(self, n):
+        pass
+
+    def get_spectral_chunks(self):
+        return 0
+
+    def close(self):
+        pass
+
+
+def shard_ensemble(pkg, inp, **kw):
+    """configure(Ensemble(ncol_local, ...), inp) for a rank's block of columns; EmptyShard when the block is empty."""
+    if inp["ncol"] == 0:
+        return EmptyShard()
+    return pkg.configure(pkg.Ensemble(inp["ncol"], **kw), inp)
+
+
 def gather_state(local_packed, ncol_total, world, dist=None):
     """All-gathers the packed [ncol_local][nlev] state blocks into [ncol_total][nlev] on every rank.
     `local_packed` is a torch tensor on the rank's device (or CPU for gloo).  Shards are padded to

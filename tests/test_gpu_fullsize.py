@@ -454,6 +454,26 @@ def test_two_ranks_with_hip_compute_equal_one_rank(pkg, tmp_path):
     assert np.ptp(a[:, 20]) > 0.1  # the perturbed columns differ: a rank-order mix-up would show
 
 
+def test_a_rank_without_columns_creates_no_handle_and_joins_the_collectives(pkg, tmp_path):
+    """3 columns on 4 ranks (HIP compute, gloo): rank 3's block is empty.  rcm_create refuses zero columns
+    (test_gpu_parity), so that rank makes no handle (distributed.EmptyShard) but still joins the warm-up gather, the
+    barriers, the final all-gather and the all-reduce of the time: rc 0, one JSON line, the gathered [3][21] state
+    equal to the one-rank run.  The same for the equilibrium driver's residual all-reduce.  (9 columns on 8 ranks
+    -- ranks 5..7 empty -- runs on CPU over gloo in tests/test_multirank_cpu.py; the box allows 6 GPU processes.)"""
+    common = ["--ncol", "3", "--nodes", "2049", "--steps", "2", "--warmup", "1", "--no-cpu-baseline"]
+    one, four = str(tmp_path / "one.npy"), str(tmp_path / "four.npy")
+    d1 = _bench(common + ["--dump-state", one])
+    d4 = _bench(common + ["--gpus", "4", "--backend", "gloo", "--dump-state", four], nproc=4)
+    assert d4["n_gpus"] == 4 and d4["config"]["columns_per_gpu"] == 1 and d4["config"]["columns_total"] == 3
+    a, b = np.load(one), np.load(four)
+    assert a.shape == b.shape == (3, 21) and np.isfinite(a).all() and H.max_abs(a, b) <= 1e-10
+    eq = ["--ncol", "3", "--nodes", "1025", "--tol", "0.2", "--check-every", "10", "--max-steps", "600"]
+    e1 = _equilibrium_example(eq + ["--save-state", one])
+    e4 = _equilibrium_example(eq + ["--backend", "gloo", "--save-state", four], nproc=4)
+    assert e1["converged"] and e4["converged"] and e4["ranks"] == 4 and e1["steps"] == e4["steps"]
+    assert H.max_abs(np.load(one), np.load(four)) <= 1e-10
+
+
 def test_bench_gpus_2_without_a_launcher_starts_its_own(pkg, tmp_path):
     """`python bench.py --gpus 2 ...` with NO torch.distributed.run in front (the form the driver used for N = 1 in
     round 2): bench.py starts the launcher itself as a child process before touching the GPU, the child's one JSON

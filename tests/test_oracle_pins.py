@@ -275,6 +275,13 @@ def test_library_exports_every_declared_symbol(rcm):
     for n in sorted(names):
         assert hasattr(L, n), f"{n} declared in include/rcm.h but not exported"
     assert L.rcm_abi_version() == 2
+    # ... and NOTHING else: the production library's dynamic symbol table is the header, symbol for symbol
+    # (csrc/rcm_exports.map; kernels, device stubs, namespace rcm and the test-side rcm_dbg_* / step-fusion entry
+    # points of the -DRCM_WITH_VARIANTS build are not part of the boundary)
+    import subprocess
+    out = subprocess.run(["nm", "-D", "--defined-only", rcm.LIB_PATH], capture_output=True, text=True, check=True).stdout
+    exported = {ln.split()[-1] for ln in out.splitlines() if ln.strip()}
+    assert exported == names, (sorted(exported - names), sorted(names - exported))
 
 
 def test_no_gpu_means_loud_failure_not_fallback(rcm):
