@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define RCM_ABI_VERSION 2
+#define RCM_ABI_VERSION 3
 
 #define RCM_OK 0
 #define RCM_ERR_ARG (-1)    /* bad argument / unsupported size            */
@@ -192,6 +192,14 @@ int rcm_get_spectral_chunks(rcm_ensemble *h);
  * the last reset, and resets. */
 int rcm_set_rt_timing(rcm_ensemble *h, int enable);
 int rcm_get_rt_timing(rcm_ensemble *h, double *ms_total, int *launches);
+
+/* Measurement utility, no handle needed (SURVEY.md section 8d asks for the HBM peak MEASURED on the box, next to
+ * the vendor's 8 TB/s): streams two device buffers of `bytes` each (>= 64 MiB; use >= 1 GiB so that the 256 MiB
+ * Infinity Cache cannot serve them) `reps` times with 16-byte accesses per lane and returns the best pass:
+ *   copy_gbs  dst = src, bytes read + bytes written per second   [GB/s]  (the figure a "float4 copy" quotes)
+ *   read_gbs  read-only pass (a sum), bytes read per second       [GB/s]  (what streaming absorption tables is)
+ * Either output may be NULL. */
+int rcm_measure_hbm_bandwidth(int device, size_t bytes, int reps, double *copy_gbs, double *read_gbs);
 
 /* ------------------------------------------------------------------------------------------
  * Host-side pieces of the reference driver, kept so that rcm_main is a drop-in for main().

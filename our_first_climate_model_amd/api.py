@@ -69,6 +69,7 @@ def _configure(L):
     L.rcm_get_spectral_chunks.argtypes = [vp]
     L.rcm_set_rt_timing.argtypes = [vp, C.c_int]
     L.rcm_get_rt_timing.argtypes = [vp, _dp, _ip]
+    L.rcm_measure_hbm_bandwidth.argtypes = [C.c_int, C.c_size_t, C.c_int, _dp, _dp]
     L.rcm_atm_load.argtypes = [C.c_char_p, C.c_int, _dp, _ip, _ip]
     L.rcm_column_init.argtypes = [C.c_int, _dp, C.c_double, C.c_double] + [_dp] * 6
     L.rcm_solar_setup.argtypes = [C.c_double, C.c_double, C.c_int, C.c_double, C.c_double, C.c_double,
@@ -83,6 +84,16 @@ def _configure(L):
     return L
 
 
+
+
+def measure_hbm_bandwidth(device=0, nbytes=1 << 30, reps=5, library=None):
+    """rcm_measure_hbm_bandwidth: (copy GB/s counting read + written bytes, read-only GB/s) of two `nbytes` buffers."""
+    L = library or lib()
+    c, r = C.c_double(0.0), C.c_double(0.0)
+    rc = L.rcm_measure_hbm_bandwidth(device, nbytes, reps, C.byref(c), C.byref(r))
+    if rc != 0:
+        raise RcmError(rc, L.rcm_last_error().decode())
+    return c.value, r.value
 
 
 def load_library(path):

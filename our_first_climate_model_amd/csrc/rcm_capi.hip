@@ -4,6 +4,7 @@
 #include <dlfcn.h>
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -48,6 +49,7 @@ struct rcm_ensemble {
   int user_chunks = 0;
   int fusion = -1;  // repwvl whole-step kernel k_step_repwvl: -1 automatic, 0 never, 1 always
   int exp_variant = 1, cube = 1, planck_fast = 1, pair = 1, flat = 1;
+  int lds_pad = 0;  // -DRCM_EXPERIMENT builds: dynamic LDS bytes added to the lbl launch (bounds the blocks per CU)
   std::vector<double> plevel, player, conv;
   std::vector<void *> allocs;
   Dev d{};
@@ -323,7 +325,12 @@ int ensure_partials(rcm_ensemble *h) {
 template <int CUBE>
 void launch_rt_pair(rcm_ensemble *h, int blocks) {
   if (h->mode == rcm::MODE_LBL) {
-    hipLaunchKernelGGL((rcm::k_rt_lbl_pair<CUBE>), dim3(blocks), dim3(64 * rcm::WPB), 0, h->stream, h->d);
+#ifdef RCM_EXPERIMENT
+    if (h->lds_pad > 0)
+      (void)hipFuncSetAttribute(reinterpret_cast<const void *>(rcm::k_rt_lbl_pair<CUBE>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, h->lds_pad);
+#endif
+    hipLaunchKernelGGL((rcm::k_rt_lbl_pair<CUBE>), dim3(blocks), dim3(64 * rcm::WPB), h->lds_pad, h->stream, h->d);
   } else if (use_flat(h)) {
     const int maxc = (rcm::FWPB * 32 - 1) / h->d.n_wvl + 2;  // columns the consecutive items of a block can touch
     const long waves = ((long)h->ncol * h->d.n_wvl + 31) / 32;
@@ -517,6 +524,9 @@ int rcm_create(int ncol, int nlayer, int nangle, int device, void *stream, rcm_e
   rcm_ensemble *h = new (std::nothrow) rcm_ensemble();
   if (!h) return fail(RCM_ERR_NOMEM, "rcm_create: out of memory");
   h->ncol = ncol, h->nlayer = nlayer, h->nangle = nangle, h->device = device;
+#ifdef RCM_EXPERIMENT  // A/B builds of tools/build_variants.py only
+  if (const char *v = std::getenv("RCM_LDS_PAD")) h->lds_pad = std::atoi(v);
+#endif
 #ifdef RCM_WITH_VARIANTS  // kernel selection by environment: test-side library only
   if (const char *v = std::getenv("RCM_EXP_VARIANT")) h->exp_variant = std::atoi(v) ? 1 : 0;
   if (const char *v = std::getenv("RCM_CUBE")) h->cube = std::atoi(v) ? 1 : 0;
@@ -1216,6 +1226,76 @@ int rcm_get_rt_timing(rcm_ensemble *h, double *ms_total, int *launches) try {
   if (ms_total) *ms_total = total;
   if (launches) *launches = (int)h->events_used;
   h->events_used = 0;
+  return RCM_OK;
+} RCM_ABI_CATCH
+
+// ---- measured HBM bandwidth (bench.py: roofline.peak_measured) -------------------------------------------------
+namespace {
+// Geometries found fastest on gfx950 by tools/ubench/stream_bw.hip (2 GiB buffers): the copy as ONE 16-byte piece per
+// lane and no loop (6.42 TB/s read + write; grid-stride loops of any unroll: 4.4 - 5.8); the read-only pass as
+// non-temporal loads, 8 independent pieces per lane and iteration, 16 384 blocks (6.56 TB/s; plain loads 5.0 - 5.9).
+typedef double rcm_d2 __attribute__((ext_vector_type(2)));
+__global__ __launch_bounds__(256) void k_stream_copy(const rcm_d2 *__restrict__ src, rcm_d2 *__restrict__ dst, size_t n) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) dst[i] = src[i];
+}
+__global__ __launch_bounds__(256) void k_stream_read(const rcm_d2 *__restrict__ src, double *sink, size_t n) {
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  double a = 0.0, b = 0.0;
+  for (; i + 7 * stride < n; i += 8 * stride) {
+    rcm_d2 v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) v[u] = __builtin_nontemporal_load(&src[i + u * stride]);
+#pragma unroll
+    for (int u = 0; u < 8; ++u) a += v[u].x, b += v[u].y;
+  }
+  for (; i < n; i += stride) a += src[i].x, b += src[i].y;
+  if (a + b == 1.2345e300) sink[0] = a;  // keeps the loads; never true for the zero-filled buffer
+}
+}  // namespace
+
+int rcm_measure_hbm_bandwidth(int device, size_t bytes, int reps, double *copy_gbs, double *read_gbs) try {
+  if (bytes < ((size_t)64 << 20) || reps < 1 || reps > 1000) return fail(RCM_ERR_ARG, "rcm_measure_hbm_bandwidth: bytes >= 64 MiB, 1 <= reps <= 1000");
+  HIPCK(hipSetDevice(device));
+  struct Bufs {  // freed on every way out
+    void *a = nullptr, *b = nullptr;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    ~Bufs() {
+      if (a) (void)hipFree(a);
+      if (b) (void)hipFree(b);
+      if (e0) (void)hipEventDestroy(e0);
+      if (e1) (void)hipEventDestroy(e1);
+    }
+  } m;
+  const size_t n = bytes / sizeof(rcm_d2);
+  if ((n + 255) / 256 > 0x7fffffffull) return fail(RCM_ERR_ARG, "rcm_measure_hbm_bandwidth: at most 8 TiB");
+  HIPCK(hipMalloc(&m.a, n * sizeof(rcm_d2)));
+  HIPCK(hipMalloc(&m.b, n * sizeof(rcm_d2)));
+  HIPCK(hipMemset(m.a, 0, n * sizeof(rcm_d2)));
+  HIPCK(hipMemset(m.b, 0, n * sizeof(rcm_d2)));
+  HIPCK(hipEventCreate(&m.e0));
+  HIPCK(hipEventCreate(&m.e1));
+  double best_copy = 0.0, best_read = 0.0;
+  for (int r = 0; r <= reps; ++r) {  // r = 0 warms up
+    float ms = 0.f;
+    HIPCK(hipEventRecord(m.e0, nullptr));
+    hipLaunchKernelGGL(k_stream_copy, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, nullptr, (const rcm_d2 *)m.a,
+                       (rcm_d2 *)m.b, n);
+    HIPCK(hipEventRecord(m.e1, nullptr));
+    HIPCK(hipEventSynchronize(m.e1));
+    HIPCK(hipEventElapsedTime(&ms, m.e0, m.e1));
+    if (r && ms > 0.f) best_copy = std::max(best_copy, 2.0 * (double)(n * sizeof(rcm_d2)) / (ms * 1e-3) / 1e9);
+    HIPCK(hipEventRecord(m.e0, nullptr));
+    hipLaunchKernelGGL(k_stream_read, dim3(16384), dim3(256), 0, nullptr, (const rcm_d2 *)m.a, (double *)m.b, n);
+    HIPCK(hipEventRecord(m.e1, nullptr));
+    HIPCK(hipEventSynchronize(m.e1));
+    HIPCK(hipEventElapsedTime(&ms, m.e0, m.e1));
+    if (r && ms > 0.f) best_read = std::max(best_read, (double)(n * sizeof(rcm_d2)) / (ms * 1e-3) / 1e9);
+  }
+  HIPCK(hipGetLastError());
+  if (copy_gbs) *copy_gbs = best_copy;
+  if (read_gbs) *read_gbs = best_read;
   return RCM_OK;
 } RCM_ABI_CATCH
 

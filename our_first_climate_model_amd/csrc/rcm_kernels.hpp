@@ -600,8 +600,11 @@ __global__ __launch_bounds__(64 * WPB, RCM_PAIR_LB) void k_rt_lbl_pair(Dev d) {
   PairLds &s = s_col[wib];
   double(*st)[64] = s_stage[wib];
 
+  RCM_PT_STAMP(0);
   lbl_pair_image(d, col, lane, s);
   __syncthreads();
+  RCM_PT_STAMP(1);
+  [[maybe_unused]] int pass = 0;  // (stamps only)
 
   // reciprocal of the column's coldest / warmest temperature (for the once-per-band Planck regime test)
   double rTmin = 0.0, rTmax = 1e300;
@@ -629,6 +632,7 @@ __global__ __launch_bounds__(64 * WPB, RCM_PAIR_LB) void k_rt_lbl_pair(Dev d) {
     lbl_pair_tau(s, p, ad.sbase, ad.row0 + (unsigned)b * 8u, ad.rstep, st, lane);
 #pragma unroll
     for (int k = 0; k < NH; ++k) tau[k] = st[k][lane];
+    RCM_PT_STAMP(2 + 3 * (pass < 19 ? pass : 19));
     // ---- band Planck source of the lane's ten layers and of the surface (cplkavg.cpp:124-243)
     const double wnumhi = d.lbl_wnum[b];      // cplkavg.cpp:141
     const double wnumlo = d.lbl_wnum[b + 1];  // cplkavg.cpp:142
@@ -666,10 +670,14 @@ __global__ __launch_bounds__(64 * WPB, RCM_PAIR_LB) void k_rt_lbl_pair(Dev d) {
 #pragma unroll
     for (int k = 0; k < NH; ++k) B[k] = st[k][lane];
     const double Linit = p ? st[NH][lane] : 0.0;  // main.cpp:300-301
+    RCM_PT_STAMP(3 + 3 * (pass < 19 ? pass : 19));
     pair_all_angles<PairLbl, CUBE>(d, tau, B, Linit, st, lane, acc1, acc2);
+    RCM_PT_STAMP(4 + 3 * (pass < 19 ? pass : 19));
+    ++pass;
   }
 
   store_pair_partial<PairLbl>(d, col, chunk, lane, valid, acc1, acc2);
+  RCM_PT_STAMP(63);
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -274,7 +274,7 @@ def test_library_exports_every_declared_symbol(rcm):
     L = rcm.lib()
     for n in sorted(names):
         assert hasattr(L, n), f"{n} declared in include/rcm.h but not exported"
-    assert L.rcm_abi_version() == 2
+    assert L.rcm_abi_version() == 3
     # ... and NOTHING else: the production library's dynamic symbol table is the header, symbol for symbol
     # (csrc/rcm_exports.map; kernels, device stubs, namespace rcm and the test-side rcm_dbg_* / step-fusion entry
     # points of the -DRCM_WITH_VARIANTS build are not part of the boundary)
