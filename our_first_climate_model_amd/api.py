@@ -27,6 +27,16 @@ def _p(a):
     return None if a is None else a.ctypes.data_as(_dp)
 
 
+def _take(ptr, shape):
+    """A numpy copy of a malloc'd double block the library handed over (np.ctypeslib.as_array builds a ctypes array
+    type per call and needs seconds for 10^7 elements; a buffer view of the address does not)."""
+    n = int(np.prod(shape))
+    if n == 0:
+        return np.zeros(shape)
+    buf = (C.c_double * n).from_address(C.addressof(ptr.contents))
+    return np.frombuffer(buf, dtype=np.float64, count=n).reshape(shape).copy()
+
+
 def _f64(a, shape=None, name="array"):
     a = np.ascontiguousarray(a, dtype=np.float64)
     if shape is not None and a.shape != tuple(shape):
@@ -170,8 +180,8 @@ def ascii_file2xy2D(path):
     st = lib().rcm_ascii_file2xy2D(os.fsencode(path), C.byref(nx), C.byref(ny), C.byref(x), C.byref(y))
     if st != 0:
         return st, None, None
-    xs = np.ctypeslib.as_array(x, (nx.value,)).copy()
-    ys = np.ctypeslib.as_array(y, (nx.value, max(ny.value, 1))).copy()[:, :ny.value]
+    xs = _take(x, (nx.value,))
+    ys = _take(y, (nx.value, max(ny.value, 1)))[:, :ny.value]
     lib().rcm_free(x)
     lib().rcm_free(y)
     return 0, xs, ys
@@ -190,8 +200,8 @@ def lbl_cache_read(path):
     n, nl = C.c_int(0), C.c_int(0)
     w, t = _dp(), _dp()
     _ck(lib().rcm_lbl_cache_read(os.fsencode(path), C.byref(n), C.byref(nl), C.byref(w), C.byref(t)))
-    wvl = np.ctypeslib.as_array(w, (n.value,)).copy()
-    tabs = np.ctypeslib.as_array(t, (NSPEC_LBL, n.value, nl.value)).copy()
+    wvl = _take(w, (n.value,))
+    tabs = _take(t, (NSPEC_LBL, n.value, nl.value))
     lib().rcm_free(w)
     lib().rcm_free(t)
     return wvl, [tabs[s] for s in range(NSPEC_LBL)]
@@ -204,7 +214,7 @@ def read_rtab(path):
     _ck(lib().rcm_rtab_load(os.fsencode(path), dims, C.byref(blob)))
     nt, ns, nw, n_p = (int(v) for v in dims)
     n = n_p + n_p + nt + ns * n_p + nw + nw + nt * ns * nw * n_p
-    a = np.ctypeslib.as_array(blob, (n,)).copy()
+    a = _take(blob, (n,))
     lib().rcm_free(blob)
     o = 0
 

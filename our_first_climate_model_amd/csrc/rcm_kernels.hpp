@@ -582,6 +582,54 @@ __device__ __forceinline__ void lbl_pair_tau(const PairLds &s, int p, const char
   }
 }
 
+// Reciprocals of the column's coldest and warmest temperature (for the once-per-band Planck regime test).
+__device__ __forceinline__ void lbl_pair_trange(const PairLds &s, double &rTmin, double &rTmax) {
+  rTmin = 0.0, rTmax = 1e300;
+  for (int k = 0; k <= NH; ++k) {
+    rTmin = fmax(rTmin, fmax(s.rT[0][k], s.rT[1][k]));
+    rTmax = fmin(rTmax, fmin(s.rT[0][k], s.rT[1][k]));
+  }
+  if (!(rTmax > 0.0)) rTmax = 0.0;  // T < 1e-4 or NaN somewhere: never the fast path
+}
+
+// Band Planck source of the lane's ten layers and of the surface (cplkavg.cpp:124-243) for band b, into the
+// lane's staging column st[0..NH][lane].
+__device__ __forceinline__ void lbl_pair_planck(const Dev &d, const PairLds &s, int p, long b, double rTmin, double rTmax,
+                                                double (*st)[64], int lane) {
+  const double wnumhi = d.lbl_wnum[b];      // cplkavg.cpp:141
+  const double wnumlo = d.lbl_wnum[b + 1];  // cplkavg.cpp:142
+  const double c2lo = 1.438786 * wnumlo, c2hi = 1.438786 * wnumhi;  // cplkavg.cpp:152-153
+  // gate of the fast path only (the slow path repeats cplkavg.cpp:155 itself): a shade inside
+  // (wnumhi - wnumlo) / wnumhi < 1.e-2, without the division
+  const bool narrow = wnumhi - wnumlo < 0.999e-2 * wnumhi;
+  // Is every one of the column's 21 temperatures in the narrow-band regime for this lane's band
+  // (hh = (c2hi-c2lo)/T < kHhFast, eps < v < 700)?  Decided once per band from Tmin/Tmax with a 0.1 %
+  // margin; when the whole wave agrees the Planck loop runs branch-free.
+  const bool lane_fast = narrow && (c2hi - c2lo) * rTmin < 0.999 * kHhFast && c2hi * rTmin < 699.0 &&
+                         c2lo * rTmax > 1e-15;
+  if (RCM_PLK_HOIST && __all(lane_fast)) {
+    const double c2mid = 0.5 * (c2lo + c2hi), dc2 = c2hi - c2lo;
+#pragma unroll RCM_PAIR_PLK_UNROLL
+    for (int k = 0; k <= NH; ++k) {
+      const double t = s.T[p][k], rT = s.rT[p][k];
+#if RCM_PLK_XM_FAST  // x at the band centre as c2mid * (1/T): two roundings instead of the correctly rounded quotient
+      (void)t;
+      st[k][lane] = cplkavg_fast_mid(c2mid * rT, dc2 * rT, s.pc[p][k]);
+#else
+      st[k][lane] = cplkavg_fast_mid(div_by_t(c2mid, t, rT), dc2 * rT, s.pc[p][k]);
+#endif
+    }
+  } else {
+#pragma unroll 1
+    for (int k = 0; k <= NH; ++k) {
+      double Bk;
+      if (!(narrow && cplkavg_fast(c2lo, c2hi, s.T[p][k], s.rT[p][k], s.pc[p][k], &Bk)))
+        Bk = cplkavg_slow(wnumlo, wnumhi, s.T[p][k], s.tp[p][k]);
+      st[k][lane] = Bk;
+    }
+  }
+}
+
 template <int CUBE>
 __global__ __launch_bounds__(64 * WPB, RCM_PAIR_LB) void k_rt_lbl_pair(Dev d) {
   __shared__ PairLds s_col[WPB];
@@ -606,13 +654,8 @@ __global__ __launch_bounds__(64 * WPB, RCM_PAIR_LB) void k_rt_lbl_pair(Dev d) {
   RCM_PT_STAMP(1);
   [[maybe_unused]] int pass = 0;  // (stamps only)
 
-  // reciprocal of the column's coldest / warmest temperature (for the once-per-band Planck regime test)
-  double rTmin = 0.0, rTmax = 1e300;
-  for (int k = 0; k <= NH; ++k) {
-    rTmin = fmax(rTmin, fmax(s.rT[0][k], s.rT[1][k]));
-    rTmax = fmin(rTmax, fmin(s.rT[0][k], s.rT[1][k]));
-  }
-  if (!(rTmax > 0.0)) rTmax = 0.0;  // T < 1e-4 or NaN somewhere: never the fast path
+  double rTmin, rTmax;
+  lbl_pair_trange(s, rTmin, rTmax);
 
   // even lane: acc1[j] = E_down[j] (j = 0..10), acc2[k] = E_up[k] (k = 0..9)
   // odd lane:  acc1[j] = E_up[20-j] (j = 0..10), acc2[k] = E_down[20-k] (k = 0..9)
@@ -634,38 +677,7 @@ __global__ __launch_bounds__(64 * WPB, RCM_PAIR_LB) void k_rt_lbl_pair(Dev d) {
     for (int k = 0; k < NH; ++k) tau[k] = st[k][lane];
     RCM_PT_STAMP(2 + 3 * (pass < 19 ? pass : 19));
     // ---- band Planck source of the lane's ten layers and of the surface (cplkavg.cpp:124-243)
-    const double wnumhi = d.lbl_wnum[b];      // cplkavg.cpp:141
-    const double wnumlo = d.lbl_wnum[b + 1];  // cplkavg.cpp:142
-    const double c2lo = 1.438786 * wnumlo, c2hi = 1.438786 * wnumhi;  // cplkavg.cpp:152-153
-    // gate of the fast path only (the slow path repeats cplkavg.cpp:155 itself): a shade inside
-    // (wnumhi - wnumlo) / wnumhi < 1.e-2, without the division
-    const bool narrow = wnumhi - wnumlo < 0.999e-2 * wnumhi;
-    // Is every one of the column's 21 temperatures in the narrow-band regime for this lane's band
-    // (hh = (c2hi-c2lo)/T < kHhFast, eps < v < 700)?  Decided once per band from Tmin/Tmax with a 0.1 %
-    // margin; when the whole wave agrees the Planck loop runs branch-free.
-    const bool lane_fast = narrow && (c2hi - c2lo) * rTmin < 0.999 * kHhFast && c2hi * rTmin < 699.0 &&
-                           c2lo * rTmax > 1e-15;
-    if (RCM_PLK_HOIST && __all(lane_fast)) {
-      const double c2mid = 0.5 * (c2lo + c2hi), dc2 = c2hi - c2lo;
-#pragma unroll RCM_PAIR_PLK_UNROLL
-      for (int k = 0; k <= NH; ++k) {
-        const double t = s.T[p][k], rT = s.rT[p][k];
-#if RCM_PLK_XM_FAST  // x at the band centre as c2mid * (1/T): two roundings instead of the correctly rounded quotient
-        (void)t;
-        st[k][lane] = cplkavg_fast_mid(c2mid * rT, dc2 * rT, s.pc[p][k]);
-#else
-        st[k][lane] = cplkavg_fast_mid(div_by_t(c2mid, t, rT), dc2 * rT, s.pc[p][k]);
-#endif
-      }
-    } else {
-#pragma unroll 1
-      for (int k = 0; k <= NH; ++k) {
-        double Bk;
-        if (!(narrow && cplkavg_fast(c2lo, c2hi, s.T[p][k], s.rT[p][k], s.pc[p][k], &Bk)))
-          Bk = cplkavg_slow(wnumlo, wnumhi, s.T[p][k], s.tp[p][k]);
-        st[k][lane] = Bk;
-      }
-    }
+    lbl_pair_planck(d, s, p, b, rTmin, rTmax, st, lane);
     double B[NH];
 #pragma unroll
     for (int k = 0; k < NH; ++k) B[k] = st[k][lane];

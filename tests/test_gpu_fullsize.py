@@ -633,6 +633,38 @@ def test_two_handles_on_two_streams_equal_one_handle(pkg):
         one.close()
 
 
+def test_repwvl_result_under_another_sharding_agrees_to_the_documented_bound(pkg, olib):
+    """include/rcm.h (rcm_set_columns): which repwvl species are summed into one table row set is decided from the columns
+    a HANDLE holds, so a rank's shard may merge another set than the whole ensemble would.  12 columns in
+    which N2O varies only among the last four and CH4 only among the first three: the whole ensemble merges {O3}; shard
+    A (columns 0..5) merges {O3, N2O}, shard B (6..11) {O3, CH4} -- a species stops being shared in each.  The same
+    column under either sharding: optical depths <= 1e-12 relative (both also against read_tau), and after 6 steps
+    fluxes <= 2e-9 W/m2, temperatures <= 1e-9 K -- agreement to rounding, not bit for bit, as documented."""
+    rng = np.random.default_rng(11)
+    inp = H.make_inputs(pkg, "repwvl", 12, table="Reduced20")
+    gas = inp["cols"]["gas"]            # [12][9][20]: H2O 0, CO2 1, O3 2, N2O 3, CO 4, CH4 5
+    gas[8:, 3] *= rng.uniform(0.5, 2.0, (4, 1))
+    gas[:3, 5] *= rng.uniform(0.5, 2.0, (3, 1))
+    one = H.gpu_ensemble(pkg, inp)
+    parts = [H.gpu_ensemble(pkg, _columns(inp, np.arange(0, 6))), H.gpu_ensemble(pkg, _columns(inp, np.arange(6, 12)))]
+    o = H.oracle_ensemble(olib, inp)
+    differs = 0
+    for c in range(12):
+        a, b = one.get_tau_production(c), parts[c // 6].get_tau_production(c % 6)
+        np.testing.assert_allclose(a, b, rtol=1e-12, atol=0)
+        np.testing.assert_allclose(b, o.get_tau(c), rtol=1e-12, atol=0)
+        differs += int(not np.array_equal(a, b))
+    assert differs > 0     # the shards really summed other species sets (else this test checks nothing)
+    one.step(6), parts[0].step(6), parts[1].step(6)
+    s1, f1 = one.get_state(), one.get_fluxes()
+    sp = [p.get_state() for p in parts]
+    fp = [p.get_fluxes() for p in parts]
+    for k in ("Tlayer", "T_surface"):
+        assert H.max_abs(np.concatenate([x[k] for x in sp]), s1[k]) <= TEMP_TIGHT, k
+    for k in f1:
+        assert H.max_abs(np.concatenate([x[k] for x in fp]), f1[k]) <= FLUX_TIGHT, k
+
+
 def test_handles_give_their_device_memory_back(pkg):
     """create -> tables -> columns -> step -> destroy, twenty times per path: the free device memory ends where it began
     (rcm_destroy frees every buffer of the handle, the partial records and the column images included)."""

@@ -333,9 +333,32 @@ def test_config1_single_column_full_lbl_spectrum_against_oracle(pkg, olib, big):
     inp["ncol"] = 1
     inp["cols"] = {k: (v[:1] if getattr(v, "ndim", 0) >= 1 and v.shape[0] == 8 else v) for k, v in big["cols"].items()}
     g, o = H.gpu_ensemble(pkg, inp), H.oracle_ensemble(olib, inp, threads=1)
-    assert g.get_spectral_chunks() > 1000
+    assert g.get_spectral_chunks() > 1000   # 2 048 waves of two passes
     g.step(2), o.step(2)
     _check_fluxes(g, o, 1e-9)
+    _check_state(g, o)
+
+
+@pytest.mark.parametrize("ncol,n_nodes,nangle", [(1, 2049, 30), (2, 2050, 30), (1, 4100, 30), (2, 20001, 30), (1, 6000, 3),
+                                                 (2, 5000, 7), (1, 40000, 64), (3, 777, 1), (5, 3001, 2), (40, 3333, 30)])
+def test_few_column_lbl_launch_against_oracle(pkg, olib, ncol, n_nodes, nangle):
+    """The few-column launch geometry of BASELINE configs[1] (at most 4 096 waves, one or two passes each) at sizes the
+    oracle covers in seconds: ragged spectra, one / two / few / 64 angles (an odd number of schedule entries; nangle 1,
+    2, 3 have no generator pair of roots), per-column cloud forcing, steps in one call and split calls.  Written for the
+    round-4 launch experiments (profiles/README.md: a block per CU with loader waves, two angle chains per wave), kept
+    as coverage of the production kernel where those ran.  Fluxes <= 2e-9 W/m2, temperatures <= 1e-6 K."""
+    inp = H.make_inputs(pkg, "lbl", ncol, n_nodes=n_nodes, atm="fpda.lbl.atm")
+    g, o = H.gpu_ensemble(pkg, inp, nangle=nangle), H.oracle_ensemble(olib, inp, nangle=nangle)
+    assert ncol * g.get_spectral_chunks() <= 4096
+    layer = (np.arange(ncol) * 7 + 3) % 21 - 1      # -1 = no cloud
+    ctau = 0.3 + 0.1 * np.arange(ncol)
+    g.set_column_forcing(cloud_layer=layer.astype(np.int32), cloud_tau=ctau)
+    o.set_column_forcing(cloud_layer=layer.astype(np.int32), cloud_tau=ctau)
+    g.step(3), o.step(3)
+    _check_fluxes(g, o)
+    _check_state(g, o)
+    g.step(1), g.step(2), o.step(3)
+    _check_fluxes(g, o)
     _check_state(g, o)
 
 
