@@ -107,6 +107,12 @@ int rcm_set_lbl_tables(rcm_ensemble *h, int n_nodes, const double *wvl,
 int rcm_set_columns(rcm_ensemble *h, const double *Tlayer0, const double *T_surface0,
                     const double *gas, const double *rel_hum);
 
+/* repwvl: on = 0 turns the merging of shared species off (every species keeps its own table rows: ~6 % slower for a CO2
+ * sweep), so that a column's OPTICAL DEPTHS are bit-identical under any sharding of the ensemble; on = 1 (the default)
+ * merges.  May be called before or after rcm_set_columns.  (Fluxes still depend on the cut in their last bits: the
+ * flattened kernel's wave boundaries, i.e. the order of the spectral sum, move with it.) */
+int rcm_set_species_merging(rcm_ensemble *h, int on);
+
 /* Runs `nsteps` iterations of the loop body main.cpp:531-583 for every column, entirely on the
  * device, asynchronously on the handle's stream (call a getter or rcm_sync to wait):
  *   convective adjustment (:536-540) -> [i != 0: water_vapor_feedback (:562), optical depths

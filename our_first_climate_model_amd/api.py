@@ -64,6 +64,7 @@ def _configure(L):
     L.rcm_set_repwvl_tables.argtypes = [vp] + [C.c_int] * 4 + [_dp] * 6
     L.rcm_set_lbl_tables.argtypes = [vp, C.c_int, _dp, C.POINTER(_dp), _dp]
     L.rcm_set_columns.argtypes = [vp] + [_dp] * 4
+    L.rcm_set_species_merging.argtypes = [vp, C.c_int]
     L.rcm_step.argtypes = [vp, C.c_int]
     L.rcm_sync.argtypes = [vp]
     L.rcm_get_state.argtypes = [vp, _dp, _dp, _fp, _dp]
@@ -363,6 +364,10 @@ class Ensemble:
         if n < 0:
             self._ck(n)
         return n
+
+    def set_species_merging(self, on):
+        """repwvl: False keeps every species' own table rows (optical depths bit-identical under any sharding)."""
+        self._ck(self._L.rcm_set_species_merging(self.h, 1 if on else 0))
 
     def get_tau(self, col=0):
         tau = np.zeros((self.nspectral(), self.nlayer))

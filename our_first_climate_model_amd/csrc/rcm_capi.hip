@@ -66,6 +66,7 @@ struct rcm_ensemble {
   std::vector<double> t_ref;   // host copy
   std::vector<double> shared_vmr;  // [9][NL]: the profiles of the species merged into d.merged_slot (rcm_set_columns)
   unsigned shared_set = 0;         // which species those are
+  bool merge_species = true;       // rcm_set_species_merging
   int *d_ip = nullptr;
   double *d_delP = nullptr, *d_numDens = nullptr;
   // timing
@@ -199,7 +200,7 @@ int classify_species(rcm_ensemble *h, const double *gas) {
         same &= ~(1u << s);
   const unsigned old_set = h->shared_set;
   const std::vector<double> old_vmr = h->shared_vmr;
-  if (RCM_MERGE_SHARED && __builtin_popcount(same) >= 2) {
+  if (RCM_MERGE_SHARED && h->merge_species && __builtin_popcount(same) >= 2) {
     h->shared_set = same;
     h->shared_vmr.assign(gas, gas + (size_t)RCM_NSPEC_REPWVL * NL);  // column 0 = every column, for these species
     d.merged_slot = __builtin_ctz(same);
@@ -891,6 +892,18 @@ int rcm_set_columns(rcm_ensemble *h, const double *Tlayer0, const double *T_surf
   h->have_columns = true;
   h->img_valid = false;
   return RCM_OK;
+} RCM_ABI_CATCH
+
+int rcm_set_species_merging(rcm_ensemble *h, int on) try {
+  if (!h || (on != 0 && on != 1)) return fail(RCM_ERR_ARG, "rcm_set_species_merging: on must be 0 or 1");
+  if (h->merge_species == (on != 0)) return RCM_OK;
+  h->merge_species = on != 0;
+  if (h->mode != rcm::MODE_REPWVL || !h->have_columns) return RCM_OK;  // takes effect at rcm_set_columns
+  if (int rc = use_device(h)) return rc;
+  std::vector<double> gas((size_t)h->ncol * RCM_NSPEC_REPWVL * NL);  // re-classify the columns the handle holds
+  HIPCK(hipMemcpyAsync(gas.data(), h->d.gas, gas.size() * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  HIPCK(hipStreamSynchronize(h->stream));
+  return classify_species(h, gas.data());
 } RCM_ABI_CATCH
 
 int rcm_set_spectral_chunks(rcm_ensemble *h, int nchunk) try {

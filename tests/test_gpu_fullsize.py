@@ -663,6 +663,29 @@ def test_repwvl_result_under_another_sharding_agrees_to_the_documented_bound(pkg
         assert H.max_abs(np.concatenate([x[k] for x in sp]), s1[k]) <= TEMP_TIGHT, k
     for k in f1:
         assert H.max_abs(np.concatenate([x[k] for x in fp]), f1[k]) <= FLUX_TIGHT, k
+    # rcm_set_species_merging(0) on the live handles: every species keeps its own rows -> a column's optical depths
+    # no longer know the sharding (the states differ in their last bits by now: compare handles that hold the same state)
+    for e in (one, parts[0], parts[1]):
+        e.set_species_merging(False)
+    one.step(2), parts[0].step(2), parts[1].step(2)
+    s1 = one.get_state()
+    sp = [p.get_state() for p in parts]
+    assert H.max_abs(np.concatenate([x["Tlayer"] for x in sp]), s1["Tlayer"]) <= TEMP_TIGHT
+    # ... and before rcm_set_columns, from the initial state: bit-identical under either sharding, 1e-12 from read_tau
+    def unmerged(sub):
+        e = pkg.Ensemble(sub["ncol"])
+        e.set_species_merging(False)
+        return pkg.configure(e, sub)
+    one0 = unmerged(inp)
+    parts0 = [unmerged(_columns(inp, np.arange(0, 6))), unmerged(_columns(inp, np.arange(6, 12)))]
+    for c in range(12):
+        a, b = one0.get_tau_production(c), parts0[c // 6].get_tau_production(c % 6)
+        assert np.array_equal(a, b), c
+        np.testing.assert_allclose(a, o.get_tau(c), rtol=1e-12, atol=0)
+    live = H.gpu_ensemble(pkg, _columns(inp, np.arange(0, 6)))   # merged {O3, N2O} ...
+    live.set_species_merging(False)                              # ... re-classified on the handle: as if never merged
+    for c in range(6):
+        assert np.array_equal(live.get_tau_production(c), parts0[0].get_tau_production(c)), c
 
 
 def test_handles_give_their_device_memory_back(pkg):

@@ -9,7 +9,7 @@ WL=${2:-lbl}
 R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 export TMPDIR=/tmp
 cd /tmp
-B="python3 $R/bench.py --workload $WL --no-cpu-baseline"
+B="python3 $R/bench.py --workload $WL --no-cpu-baseline --no-extra"   # (the extras launch the same kernels at other sizes)
 if [ "$WL" = lbl ]; then KT="--steps 4 --warmup 1"; PM="--steps 2 --warmup 1"; CAL="--ncol 4 --steps 2 --warmup 1"
 else KT="--steps 200 --warmup 20"; PM="--steps 20 --warmup 5"; CAL="--ncol 1 --steps 20 --warmup 5"; fi
 O=$R/gpurun_out
@@ -21,6 +21,9 @@ rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/p${TAG}f -- $B $PM > $O/p${
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/p${TAG}w -- $B $PM > $O/p${TAG}w.log 2>&1 || exit 1
 rocprofv3 --pmc GRBM_GUI_ACTIVE TCC_HIT_sum TCC_MISS_sum --output-format csv -d $O/p${TAG}g -- $B $PM > $O/p${TAG}g.log 2>&1 || exit 1
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/p${TAG}f4 -- $B $CAL > $O/p${TAG}f4.log 2>&1 || exit 1
+if [ "$WL" = lbl ]; then  # configs[1]: per-kernel times of one column x the full spectrum (60 steps in one rcm_step call)
+  rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt1$TAG -- python3 $R/tools/trace_single.py > $O/kt1$TAG.log 2>&1 || exit 1
+fi
 cd $R
 timeout -k 10 600 python bench.py --workload $WL > $O/bench_$TAG.json 2> $O/bench_$TAG.err || exit 1
 cut -c1-200 $O/bench_$TAG.json
