@@ -200,7 +200,7 @@ def extra_configs(pkg, inp_lbl, dev_index, stream, read_peak_gbs, log):
     out["lbl_single_column"] = {
         "workload": f"1 column x full lbl spectrum ({nbands} bands; BASELINE.json configs[1])", "steps": 200,
         "ms_per_step": dt * 1e3, "column_timesteps_per_sec": 1.0 / dt, "rt_kernel_us": rt * 1e6,
-        "partial_records": chunks, "streamed_bytes_per_step": streamed, "streamed_GBps": streamed / rt / 1e9,
+        "spectral_chunks": chunks, "streamed_bytes_per_step": streamed, "streamed_GBps": streamed / rt / 1e9,
         "frac_of_hbm_peak": streamed / rt / 1e9 / HBM_PEAK_GBS,
         "frac_of_measured_read_peak": (streamed / rt / 1e9 / read_peak_gbs) if read_peak_gbs else None,
         "note": "the tables (105.9 MB) exceed the 32 MiB of L2 and are read once per step: streamed_GBps is real traffic "

@@ -50,6 +50,7 @@ struct rcm_ensemble {
   int fusion = -1;  // repwvl whole-step kernel k_step_repwvl: -1 automatic, 0 never, 1 always
   int exp_variant = 1, cube = 1, planck_fast = 1, pair = 1, flat = 1;
   int lds_pad = 0;  // -DRCM_EXPERIMENT builds: dynamic LDS bytes added to the lbl launch (bounds the blocks per CU)
+  int block_records = 1;  // (-DRCM_EXPERIMENT builds read RCM_BLOCK_RECORDS: 0 = the two-stage sum with k_reduce_partials)
   std::vector<double> plevel, player, conv;
   std::vector<void *> allocs;
   Dev d{};
@@ -262,6 +263,16 @@ void choose_chunks(int ncol, int nspec, int user_chunks, int *nchunk_out, int *c
 // production path unless the caller pins a chunk count or selects a reference variant.
 constexpr int kPostSlices = 32;  // blocks per column of the first-stage chunk sum (k_reduce_partials)
 
+// lbl, ONE column x many chunks (BASELINE configs[1]): the RT launch writes one record per block of 4 consecutive chunks
+// (k_rt_lbl_pair<1, 1>) and k_post sums the nchunk / 4 records itself -- no k_reduce_partials.  Measured in one
+// process (tools/ab_single.py, profiles/r04_lbl1_ab_block_records.txt): one column 67.8 - 71.1 -> 65.7 - 66.7 us per
+// step; two to four columns are 3 - 5 % SLOWER that way (a block's waves then share a column instead of a chunk, and the
+// chunk's table tile is what neighbouring waves share in L1/L2), sixteen the same: so one column only.
+bool use_block_records(const rcm_ensemble *h) {
+  return h->mode == rcm::MODE_LBL && h->pair && h->cube && h->exp_variant == 1 && h->planck_fast && h->block_records &&
+         h->d.nchunk >= 512 && h->ncol == 1;
+}
+
 bool use_flat(const rcm_ensemble *h) {
   return h->mode == rcm::MODE_REPWVL && h->flat && h->pair && h->exp_variant == 1 && h->user_chunks == 0 &&
          (long long)h->ncol * h->d.n_wvl < (1ll << 31) - 4096 &&  // 32-bit item arithmetic in the kernel
@@ -317,7 +328,7 @@ int ensure_partials(rcm_ensemble *h) {
     HIPCK(hipFree(h->slice_buf));
     h->slice_buf = nullptr;
   }
-  if (h->d.nchunk >= 512 && h->ncol <= 64)  // measured: one column x 2 048 records, k_post 18 -> 3 + 5 us
+  if (h->d.nchunk >= 512 && h->ncol <= 64 && !use_block_records(h))  // measured: one column x 2 048 records, k_post 18 -> 3 + 5 us
     HIPCK(hipMalloc((void **)&h->slice_buf, (size_t)h->ncol * kPostSlices * rcm::PSTRIDE * sizeof(double)));
   return RCM_OK;
 }
@@ -325,7 +336,10 @@ int ensure_partials(rcm_ensemble *h) {
 // The production kernels: lane pairs, cube/root-pair angle chains (CUBE = 1), own exp and narrow-band Planck.
 template <int CUBE>
 void launch_rt_pair(rcm_ensemble *h, int blocks) {
-  if (h->mode == rcm::MODE_LBL) {
+  if (h->mode == rcm::MODE_LBL && CUBE && use_block_records(h)) {
+    const int nrec = (h->d.nchunk + rcm::WPB - 1) / rcm::WPB;
+    hipLaunchKernelGGL((rcm::k_rt_lbl_pair<1, 1>), dim3((unsigned)(nrec * h->ncol)), dim3(64 * rcm::WPB), 0, h->stream, h->d);
+  } else if (h->mode == rcm::MODE_LBL) {
 #ifdef RCM_EXPERIMENT
     if (h->lds_pad > 0)
       (void)hipFuncSetAttribute(reinterpret_cast<const void *>(rcm::k_rt_lbl_pair<CUBE>),
@@ -466,8 +480,10 @@ int launch_step(rcm_ensemble *h, bool have_pre, bool next_pre) {
   if (int rc = timing_begin(h, &e1)) return rc;
   launch_rt(h, blocks);
   if (e1) HIPCK(hipEventRecord(e1, h->stream));
-  Dev dp = d;  // what k_post sums: the chunk records, or their slice sums
-  if (h->slice_buf) {
+  Dev dp = d;  // what k_post sums: the chunk records, the block records, or the slice sums
+  if (use_block_records(h)) {
+    dp.nchunk = (d.nchunk + rcm::WPB - 1) / rcm::WPB;
+  } else if (h->slice_buf) {
     const int len = (d.nchunk + kPostSlices - 1) / kPostSlices;
     hipLaunchKernelGGL(rcm::k_reduce_partials, dim3(kPostSlices, h->ncol), dim3(64 * 8), 0, h->stream, d.partial,
                        h->slice_buf, d.nchunk, len, kPostSlices);
@@ -527,6 +543,7 @@ int rcm_create(int ncol, int nlayer, int nangle, int device, void *stream, rcm_e
   h->ncol = ncol, h->nlayer = nlayer, h->nangle = nangle, h->device = device;
 #ifdef RCM_EXPERIMENT  // A/B builds of tools/build_variants.py only
   if (const char *v = std::getenv("RCM_LDS_PAD")) h->lds_pad = std::atoi(v);
+  if (const char *v = std::getenv("RCM_BLOCK_RECORDS")) h->block_records = std::atoi(v);
 #endif
 #ifdef RCM_WITH_VARIANTS  // kernel selection by environment: test-side library only
   if (const char *v = std::getenv("RCM_EXP_VARIANT")) h->exp_variant = std::atoi(v) ? 1 : 0;

@@ -630,7 +630,13 @@ __device__ __forceinline__ void lbl_pair_planck(const Dev &d, const PairLds &s, 
   }
 }
 
-template <int CUBE>
+// BR = 1 (few columns x many chunks, where a column has hundreds of records: BASELINE configs[1]): a block owns WPB
+// CONSECUTIVE chunks of ONE column and writes ONE record -- its waves' sums meet in LDS (three DPP levels inside the
+// half-rows of 8 lanes, then the half-rows and the waves in a fixed order) -- so that a column has nchunk / WPB records
+// and k_post sums them directly: the k_reduce_partials launch between the two is gone (one column x 131 071 bands:
+// 2 048 -> 512 records, 4.8 us of a 73 us step) and the wave's tail is 21 x 3 DPP steps instead of 21 x 5 butterfly
+// levels, two of which cross rows.
+template <int CUBE, int BR = 0>
 __global__ __launch_bounds__(64 * WPB, RCM_PAIR_LB) void k_rt_lbl_pair(Dev d) {
   __shared__ PairLds s_col[WPB];
   __shared__ double s_stage[WPB][NH + 1][64];
@@ -639,7 +645,8 @@ __global__ __launch_bounds__(64 * WPB, RCM_PAIR_LB) void k_rt_lbl_pair(Dev d) {
   // work item = (chunk, column), column fastest: the waves of a block and neighbouring blocks share
   // the chunk (its table tile stays in L2); a small ensemble still fills every wave slot
   const long nitem = (long)d.ncol * d.nchunk;
-  const long item_raw = (long)blockIdx.x * WPB + wib;
+  const long item_raw = BR ? ((long)(blockIdx.x / (unsigned)d.ncol) * WPB + wib) * d.ncol + blockIdx.x % (unsigned)d.ncol
+                           : (long)blockIdx.x * WPB + wib;
   const bool valid = item_raw < nitem;
   const long item = valid ? item_raw : nitem - 1;
   const int chunk = (int)(item / d.ncol);
@@ -666,7 +673,7 @@ __global__ __launch_bounds__(64 * WPB, RCM_PAIR_LB) void k_rt_lbl_pair(Dev d) {
   for (int j = 0; j < NH; ++j) acc2[j] = 0.0;
 
   const long b0 = (long)chunk * d.chunk_len;
-  const long b1 = min(b0 + (long)d.chunk_len, (long)d.nspec);
+  const long b1 = (BR && !valid) ? b0 : min(b0 + (long)d.chunk_len, (long)d.nspec);  // (BR: a wave past the last chunk adds zeros)
   const LblAddr ad = lbl_pair_addr(d, p);
 
   for (long b = b0 + PairLbl::index(lane); b < b1; b += 32) {  // main.cpp:329: 32 bands per wave pass
@@ -688,7 +695,38 @@ __global__ __launch_bounds__(64 * WPB, RCM_PAIR_LB) void k_rt_lbl_pair(Dev d) {
     ++pass;
   }
 
-  store_pair_partial<PairLbl>(d, col, chunk, lane, valid, acc1, acc2);
+  if constexpr (!BR) {
+    store_pair_partial<PairLbl>(d, col, chunk, lane, valid, acc1, acc2);
+  } else {
+    static_assert(!BR || RCM_LBL_LAYOUT == 2, "the block reduction assumes Pair<2>: half-rows of 8 lanes alternate in parity");
+    // [wave][half-row of 8 lanes][acc1[0..10], acc2[0..9]], aliased onto the staging rows (the angle loops are over)
+    double(*red)[8][2 * NH + 1] = reinterpret_cast<double(*)[8][2 * NH + 1]>(&s_stage[0][0][0]);
+    static_assert(sizeof(double) * WPB * 8 * (2 * NH + 1) <= sizeof(s_stage), "reduction rows fit the staging rows");
+    __syncthreads();  // every wave of the block is done with its staging rows
+#pragma unroll
+    for (int j = 0; j <= NH; ++j) {
+      const double v = PairLbl::template sum<3>(acc1[j]);
+      if ((lane & 7) == 0) red[wib][lane >> 3][j] = v;
+    }
+#pragma unroll
+    for (int k = 0; k < NH; ++k) {
+      const double v = PairLbl::template sum<3>(acc2[k]);
+      if ((lane & 7) == 0) red[wib][lane >> 3][NH + 1 + k] = v;
+    }
+    __syncthreads();
+    if (wib == 0 && lane < 2 * (2 * NH + 1)) {
+      const int q = lane / (2 * NH + 1), v = lane - q * (2 * NH + 1);
+      double acc = 0.0;
+      for (int w = 0; w < WPB; ++w)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) acc += red[w][2 * g + q][v];  // half-row h holds parity h & 1 (Pair<2>)
+      const int nrec = (d.nchunk + WPB - 1) / WPB;
+      double *oEd = d.partial + ((size_t)col * nrec + blockIdx.x / (unsigned)d.ncol) * PSTRIDE, *oEu = oEd + NLEV;
+      // q = 0 (layers 0..9): acc1[j] = E_down[j], acc2[k] = E_up[k];  q = 1: acc1[j] = E_up[20-j], acc2[k] = E_down[20-k]
+      if (v <= NH) (q ? oEu[NL - v] : oEd[v]) = acc;
+      else (q ? oEd[NL - (v - NH - 1)] : oEu[v - NH - 1]) = acc;
+    }
+  }
   RCM_PT_STAMP(63);
 }
 
@@ -1353,12 +1391,12 @@ __global__ __launch_bounds__(1024) void k_post(Dev d, int next_pre) {
   if (j < PSTRIDE) {
     const double *p = d.partial + (size_t)c * d.nchunk * PSTRIDE + j;
     double acc = 0.0;
-    for (int k = q; k < d.nchunk; k += 16 * P) {  // sixteen loads in flight, added in chunk order as before
-      double v[16];
+    for (int k = q; k < d.nchunk; k += 32 * P) {  // 32 loads in flight (one column x 512 block records: ONE round trip
+      double v[32];                               // per wave), added in chunk order as before
 #pragma unroll
-      for (int u = 0; u < 16; ++u) v[u] = (k + u * P < d.nchunk) ? p[(size_t)(k + u * P) * PSTRIDE] : 0.0;
+      for (int u = 0; u < 32; ++u) v[u] = (k + u * P < d.nchunk) ? p[(size_t)(k + u * P) * PSTRIDE] : 0.0;
 #pragma unroll
-      for (int u = 0; u < 16; ++u) acc += v[u];
+      for (int u = 0; u < 32; ++u) acc += v[u];
     }
     s_part[q][j] = acc;
   }
