@@ -2,7 +2,7 @@
 # TEST INFRASTRUCTURE.  Compiles the reference's own code, UNEDITED and from where it lies, into oracle/_ref/
 # (git-ignored; the .so files travel with gpurun).  Called by oracle/Makefile when the reference tree exists.
 #
-#   build_ref.sh REF_DIR            build
+#   build_ref.sh REF_DIR            build into oracle/_ref (or into $RCM_REF_OUT: the test of the hash check uses that)
 #   build_ref.sh REF_DIR --rehash   print the hash list for ref_slices.sha256 (after LOOKING at a changed reference)
 #
 # Slices are addressed by line number, so every slice is hashed first and compared with ref_slices.sha256: a
@@ -42,23 +42,24 @@ hashes() {
 }
 if [ "${2:-}" = "--rehash" ]; then hashes; exit 0; fi
 
-rm -rf _ref
+OUT=${RCM_REF_OUT:-_ref}
+rm -rf "$OUT"
 if ! diff <(hashes) ref_slices.sha256 >/dev/null; then
   echo "oracle/build_ref.sh: the reference under $REF is not the revision the line slices were cut for:" >&2
   diff <(hashes) ref_slices.sha256 >&2 || true
-  echo "nothing built (oracle/_ref removed).  Inspect the reference, re-cut the slices, then --rehash." >&2
+  echo "nothing built ($OUT removed).  Inspect the reference, re-cut the slices, then --rehash." >&2
   exit 1
 fi
 
-mkdir -p _ref
+mkdir -p "$OUT"
 CXX="g++ -O2 -w -fPIC -shared"
-$CXX -o _ref/libref_cplkavg.so "$REF/cplkavg.cpp" -lm
-$CXX -I"$REF/lbl.arts" -o _ref/libref_ascii.so "$REF/lbl.arts/ascii.cpp" -lm
-{ slice "$MAIN" '12,21p;25,344p'; cat ref_main_shim.inc; } | $CXX -x c++ -o _ref/libref_main.so - -lm
-{ slice "$RT" '2,4p;6p;10p;13,45p'; cat ref_lowerpos_shim.inc; } | $CXX -x c++ -o _ref/libref_lowerpos.so -
+$CXX -o "$OUT"/libref_cplkavg.so "$REF/cplkavg.cpp" -lm
+$CXX -I"$REF/lbl.arts" -o "$OUT"/libref_ascii.so "$REF/lbl.arts/ascii.cpp" -lm
+{ slice "$MAIN" '12,21p;25,344p'; cat ref_main_shim.inc; } | $CXX -x c++ -o "$OUT"/libref_main.so - -lm
+{ slice "$RT" '2,4p;6p;10p;13,45p'; cat ref_lowerpos_shim.inc; } | $CXX -x c++ -o "$OUT"/libref_lowerpos.so -
 { slice "$RT" '2,4p;6p;10p;13,45p'; section HEAD; section A
   slice "$RT" '55,111p';  section B
   slice "$RT" '124,141p'; slice "$RT" '153,168p'; section C
   slice "$RT" '178,206p'; section D
-  slice "$RT" '210,262p'; section E; } | $CXX -x c++ -o _ref/libref_readtau.so -
-echo "built oracle/_ref from $REF"
+  slice "$RT" '210,262p'; section E; } | $CXX -x c++ -o "$OUT"/libref_readtau.so -
+echo "built $OUT from $REF"

@@ -559,3 +559,37 @@ def test_oracle_against_the_committed_reference_vectors(olib, golden):
             got = np.concatenate([[i, s["timestep"][0], s["T_surface"][0]], s["Tlayer"][0], f["E_down"][0], f["E_up"][0],
                                   f["dE"][0]])
             assert got.tolist() == row.tolist(), (table, i)
+
+
+def test_build_ref_refuses_a_reference_whose_lines_have_moved(tmp_path):
+    """the reference is compiled by LINE SLICES, so oracle/build_ref.sh hashes every slice (and every range it
+    deliberately skips) against oracle/ref_slices.sha256 before g++ sees anything.  A tree in which repwvl_thermal.cpp
+    is another file (a symlink to the reference's cplkavg.cpp: nothing is copied) must fail loudly, name the slices
+    that differ and leave NO library behind -- not even a stale one: the output directory is removed first."""
+    import subprocess
+    REF = "/root/reference"
+    if not os.path.isfile(os.path.join(REF, "main.cpp")):
+        pytest.skip("reference tree absent")
+    script = os.path.join(ol.ROOT, "oracle", "build_ref.sh")
+    fake = tmp_path / "ref"
+    (fake / "repwvl_V2.01_cpp").mkdir(parents=True)
+    (fake / "lbl.arts").mkdir()
+    os.symlink(os.path.join(REF, "main.cpp"), fake / "main.cpp")
+    os.symlink(os.path.join(REF, "cplkavg.cpp"), fake / "cplkavg.cpp")
+    os.symlink(os.path.join(REF, "lbl.arts", "ascii.cpp"), fake / "lbl.arts" / "ascii.cpp")
+    os.symlink(os.path.join(REF, "cplkavg.cpp"), fake / "repwvl_V2.01_cpp" / "repwvl_thermal.cpp")   # the "moved" file
+    out = tmp_path / "out"
+    out.mkdir()
+    (out / "libref_readtau.so").write_bytes(b"stale")
+    env = dict(os.environ, RCM_REF_OUT=str(out))
+    r = subprocess.run(["bash", script, str(fake)], capture_output=True, text=True, env=env, timeout=300)
+    assert r.returncode != 0
+    assert "not the revision the line slices were cut for" in r.stderr
+    for name in ("rt_prelude", "rt_210_262", "rt_skipped"):
+        assert name in r.stderr
+    assert not out.exists()                       # the stale library went with the directory
+    # the unmodified reference builds into the same place (five libraries)
+    r = subprocess.run(["bash", script, REF], capture_output=True, text=True, env=env, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert sorted(os.listdir(out)) == ["libref_ascii.so", "libref_cplkavg.so", "libref_lowerpos.so", "libref_main.so",
+                                       "libref_readtau.so"]
