@@ -81,11 +81,12 @@ def _subset(inp, n):
 
 def cpu_baseline(pkg, inp_full, workload, log):
     """The CPU oracle (a port of the reference, bit-identical to the reference's compiled functions wherever those
-    exist: tests/test_reference_pins.py; the full step needs read_tau, which needs netcdf and cannot be built
-    here, and the lbl composition has no reference driver -- hence kind "port") timed on this host's cores on a
-    bounded sample of the same workload: all cores and one core (the reference is single-threaded), full step and
-    radiative transfer alone.  For repwvl the reference's OWN compiled radiative_transfer
-    (oracle/_ref/libref_main.so) is timed beside the port when the prebuilt library is there."""
+    exist -- since round 4 read_tau included: tests/test_reference_pins.py; the lbl composition has no reference
+    driver, and the all-core figure needs the port's OpenMP loop over columns -- hence kind "port") timed on this
+    host's cores on a bounded sample of the same workload: all cores and one core (the reference is single-threaded),
+    full step and radiative transfer alone.  For repwvl the reference's OWN compiled code
+    (oracle/_ref/libref_main.so, libref_readtau.so) is timed beside the port when the prebuilt libraries are there:
+    radiative_transfer alone and the full step of main.cpp:536-581, one column on one core."""
     import ctypes as C
     import numpy as np
     sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -158,6 +159,9 @@ def cpu_baseline(pkg, inp_full, workload, log):
             for _ in range(reps):
                 ol.ref_radiative_transfer(ref, tau, wvl, wgt, Tl, float(st["T_surface"][0]), float(inp_full["solar"]))
             out["single_core_rt_only_reference_value"] = reps / (time.perf_counter() - t0)
+        full = reference_repwvl_step_rate(log)
+        if full is not None:  # the reference's own full step (main.cpp:536-581 with its compiled read_tau), table in memory
+            out["single_core_reference_full_step_value"] = full
     return out
 
 
@@ -220,6 +224,52 @@ def extra_configs(pkg, inp_lbl, dev_index, stream, read_peak_gbs, log):
         "note": "full line with roofline and cpu_baseline: python bench.py --workload repwvl100"}
     log(f"extra repwvl100: {dt * 1e3:.4f} ms/step, RT {rt * 1e3:.4f} ms, {ncol / dt / 1e6:.2f} M column-timesteps/s")
     return out
+
+
+def reference_repwvl_step_rate(log, steps=20):
+    """The REFERENCE's own compiled functions (oracle/_ref/libref_main.so + libref_readtau.so: main.cpp:25-344 and the
+    netCDF-free statements of read_tau, compiled unedited by oracle/build_ref.sh; prebuilt, they travel with the
+    snapshot) driven in the order of main.cpp:536-581 for ONE column x Reduced100 on one core: convective adjustment,
+    water-vapour feedback, read_tau (table resident in memory -- the reference re-reads the file every step, which
+    is not timed here), cloud, radiative_transfer, time step, thermodynamics.  Returns column-timesteps/s or None
+    when the libraries were not built (no reference tree at build time)."""
+    import numpy as np
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle_lib as ol  # noqa: E402  (test infrastructure; timed as the CPU baseline, after the timed region)
+    ref, rt = ol.load_ref_main(), ol.load_ref_readtau()
+    if ref is None or rt is None:
+        return None
+    olib, _p = ol.load(), ol._p
+    golden = os.path.join(ROOT, "tests", "golden")
+    atm, _ = ol.atm_load(olib, os.path.join(golden, "test.atm"))
+    ci = ol.column_init(olib, atm, 1.0, 1.0)
+    t = ol.read_rtab(os.path.join(golden, "Reduced100Forcing.rtab"))
+    sol = np.zeros(7)
+    ref.ref_solar(_p(sol))
+    T, Ts, vmr, theta = ci["Tlayer"].copy(), 288.2, ci["vmr9"].copy(), np.zeros(20)
+
+    def tau_of():
+        tau, _, _ = ol.ref_read_tau(rt, t, ci["plevel"], T, vmr)
+        ref.ref_cloud_into_tau(_p(tau), t["n_wvl"])
+        return tau
+    tau = tau_of()
+    t0 = time.perf_counter()
+    for i in range(steps + 1):
+        ref.ref_convective_adjustment(_p(T), _p(theta), _p(ci["conv"]))
+        if i != 0:
+            h2o = np.zeros(20)
+            ref.ref_water_vapor_feedback(_p(T), _p(ci["rel_hum"]), _p(ci["player"]), _p(h2o))
+            vmr[0] = h2o
+            tau = tau_of()
+        Ed, Eu, dE = ol.ref_radiative_transfer(ref, tau, t["wvl"], t["weight"], T, Ts, sol[6])
+        dt = ref.ref_calculate_timestep(50.0, _p(dE))
+        Ts = ref.ref_thermodynamics(_p(T), 50.0, _p(dE), dt, _p(ci["conv"]))
+        if i == 0:
+            t0 = time.perf_counter()  # iteration 0 has no read_tau (main.cpp:549): time iterations 1..steps
+    rate = steps / (time.perf_counter() - t0)
+    log(f"cpu reference (compiled main.cpp + read_tau), one column x Reduced100, 1 core: {1e3 / rate:.3f} ms per step")
+    assert 250.0 < Ts < 350.0
+    return rate
 
 
 def committed_counters(workload):
@@ -480,6 +530,9 @@ def main():
             if "cpu_baseline" in out and args.nodes == 131072:  # the oracle's one-thread figure IS configs[1]'s workload
                 out["extra"]["lbl_single_column"]["cpu_single_core_column_timesteps_per_sec"] = \
                     out["cpu_baseline"]["single_core_value"]
+            if "cpu_baseline" in out:  # configs[2] has a reference CPU path: the reference's own compiled code, one core
+                out["extra"]["repwvl100"]["cpu_reference_single_core_column_timesteps_per_sec"] = \
+                    reference_repwvl_step_rate(log)
         sys.stdout.flush()
         os.dup2(stdout_fd, 1)
         print(json.dumps(out), flush=True)

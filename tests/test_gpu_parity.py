@@ -977,3 +977,12 @@ def test_gpu_tau_against_the_committed_reference_tau(pkg, golden, table):
         if col < 2:                                                    # test.atm itself: plain relative
             np.testing.assert_allclose(ref_form, want[col], rtol=1e-12, atol=0)
             np.testing.assert_allclose(prod, want[col], rtol=1e-12, atol=0)
+
+
+def test_measured_hbm_bandwidth_is_plausible(pkg):
+    """rcm_measure_hbm_bandwidth (bench.py: roofline.peak_measured): 2 x 512 MiB, beyond the Infinity Cache.  Between 3 and
+    8 TB/s on an MI355X (MI355X_MICROARCH.md: 6.29 measured, 8.0 spec); the read-only pass is not slower than 80 % of
+    the copy's byte rate."""
+    copy_gbs, read_gbs = pkg.measure_hbm_bandwidth(0, 512 << 20, 3)
+    assert 3000.0 < copy_gbs < 8000.0 and 3000.0 < read_gbs < 8000.0, (copy_gbs, read_gbs)
+    assert read_gbs > 0.8 * copy_gbs

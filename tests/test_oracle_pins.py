@@ -284,6 +284,15 @@ def test_library_exports_every_declared_symbol(rcm):
     assert exported == names, (sorted(exported - names), sorted(names - exported))
 
 
+def test_measurement_utility_checks_its_arguments(rcm):
+    """rcm_measure_hbm_bandwidth refuses buffers the 256 MiB Infinity Cache could serve and absurd repetition counts
+    before it touches a device (RCM_ERR_ARG, with or without a GPU)."""
+    for nbytes, reps in ((1 << 20, 3), (1 << 30, 0), (1 << 30, 100000)):
+        with pytest.raises(rcm.RcmError) as ei:
+            rcm.measure_hbm_bandwidth(0, nbytes, reps)
+        assert ei.value.code == -1
+
+
 def test_no_gpu_means_loud_failure_not_fallback(rcm):
     import torch
     if torch.cuda.is_available():
