@@ -51,6 +51,7 @@ struct rcm_ensemble {
   int exp_variant = 1, cube = 1, planck_fast = 1, pair = 1, flat = 1;
   int lds_pad = 0;  // -DRCM_EXPERIMENT builds: dynamic LDS bytes added to the lbl launch (bounds the blocks per CU)
   int block_records = 1;  // (-DRCM_EXPERIMENT builds read RCM_BLOCK_RECORDS: 0 = the two-stage sum with k_reduce_partials)
+  int flip_passes = 1;    // (-DRCM_EXPERIMENT builds read RCM_FLIP: 0 = every launch takes its passes in the same order)
   std::vector<double> plevel, player, conv;
   std::vector<void *> allocs;
   Dev d{};
@@ -476,6 +477,10 @@ int launch_step(rcm_ensemble *h, bool have_pre, bool next_pre) {
   if (!have_pre)
     hipLaunchKernelGGL(rcm::k_pre, dim3((h->ncol + rcm::WPB - 1) / rcm::WPB), dim3(64 * rcm::WPB), 0, h->stream, d, first);
   const int blocks = (int)(((long)h->ncol * d.nchunk + rcm::WPB - 1) / rcm::WPB);
+  // lbl, tables beyond the L2 (few columns: every launch streams them once): odd iterations take each wave's passes in
+  // reverse, so a launch begins with what the previous one ended with (the order of a wave's spectral sum alternates
+  // with the iteration: deterministic, last bits)
+  d.flip = (h->mode == rcm::MODE_LBL && h->flip_passes && (long)h->ncol * d.nchunk <= 8192) ? (int)(h->step_index & 1) : 0;
   hipEvent_t e1 = nullptr;
   if (int rc = timing_begin(h, &e1)) return rc;
   launch_rt(h, blocks);
@@ -544,6 +549,7 @@ int rcm_create(int ncol, int nlayer, int nangle, int device, void *stream, rcm_e
 #ifdef RCM_EXPERIMENT  // A/B builds of tools/build_variants.py only
   if (const char *v = std::getenv("RCM_LDS_PAD")) h->lds_pad = std::atoi(v);
   if (const char *v = std::getenv("RCM_BLOCK_RECORDS")) h->block_records = std::atoi(v);
+  if (const char *v = std::getenv("RCM_FLIP")) h->flip_passes = std::atoi(v);
 #endif
 #ifdef RCM_WITH_VARIANTS  // kernel selection by environment: test-side library only
   if (const char *v = std::getenv("RCM_EXP_VARIANT")) h->exp_variant = std::atoi(v) ? 1 : 0;

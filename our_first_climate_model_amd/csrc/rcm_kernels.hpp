@@ -113,6 +113,8 @@ struct Dev {
   double *Tprev;  // adjusted profile of the previous iteration
   const double *player, *conv, *ang;  // ang = [inv_mu[nangle], cw[nangle], sum of cw, schedule {a1, code}[nsched]]
   int nsched;                         // entries of the root schedule (pair_all_angles)
+  int flip;  // lbl: 1 = a wave takes its passes LAST FIRST (odd iterations of few-column runs: the passes a wave ended
+             // the previous launch with are the ones still in its XCD's L2 -- the tables, 106 MB, exceed the 32 MiB)
   double *T, *Ttau, *Tsfc, *dt, *gas, *E_down, *E_up, *dE, *partial;
   const double *rel_hum;
   float *time_h;
@@ -676,7 +678,10 @@ __global__ __launch_bounds__(64 * WPB, RCM_PAIR_LB) void k_rt_lbl_pair(Dev d) {
   const long b1 = (BR && !valid) ? b0 : min(b0 + (long)d.chunk_len, (long)d.nspec);  // (BR: a wave past the last chunk adds zeros)
   const LblAddr ad = lbl_pair_addr(d, p);
 
-  for (long b = b0 + PairLbl::index(lane); b < b1; b += 32) {  // main.cpp:329: 32 bands per wave pass
+  const long bf = b0 + PairLbl::index(lane);
+  const int npl = bf < b1 ? (int)((b1 - bf + 31) >> 5) : 0;  // passes of this lane (main.cpp:329: 32 bands per wave pass)
+  for (int i = 0; i < npl; ++i) {
+    const long b = bf + 32L * (d.flip ? npl - 1 - i : i);
     // ---- optical depths of the lane's ten layers (lbl composition + cloud, main.cpp:266-274)
     double tau[NH];
     lbl_pair_tau(s, p, ad.sbase, ad.row0 + (unsigned)b * 8u, ad.rstep, st, lane);
