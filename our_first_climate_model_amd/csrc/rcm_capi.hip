@@ -477,10 +477,10 @@ int launch_step(rcm_ensemble *h, bool have_pre, bool next_pre) {
   if (!have_pre)
     hipLaunchKernelGGL(rcm::k_pre, dim3((h->ncol + rcm::WPB - 1) / rcm::WPB), dim3(64 * rcm::WPB), 0, h->stream, d, first);
   const int blocks = (int)(((long)h->ncol * d.nchunk + rcm::WPB - 1) / rcm::WPB);
-  // lbl, tables beyond the L2 (few columns: every launch streams them once): odd iterations take each wave's passes in
-  // reverse, so a launch begins with what the previous one ended with (the order of a wave's spectral sum alternates
-  // with the iteration: deterministic, last bits)
-  d.flip = (h->mode == rcm::MODE_LBL && h->flip_passes && (long)h->ncol * d.nchunk <= 8192) ? (int)(h->step_index & 1) : 0;
+  // lbl, one column x the full spectrum (every launch streams the 106 MB of tables once, the L2 holds 32 MiB): odd
+  // iterations take each wave's passes in reverse, so a launch begins with what the previous one ended with (the order
+  // of a wave's spectral sum alternates with the iteration: deterministic, last bits)
+  d.flip = (use_block_records(h) && h->flip_passes) ? (int)(h->step_index & 1) : 0;
   hipEvent_t e1 = nullptr;
   if (int rc = timing_begin(h, &e1)) return rc;
   launch_rt(h, blocks);

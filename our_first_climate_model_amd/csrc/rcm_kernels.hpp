@@ -678,10 +678,11 @@ __global__ __launch_bounds__(64 * WPB, RCM_PAIR_LB) void k_rt_lbl_pair(Dev d) {
   const long b1 = (BR && !valid) ? b0 : min(b0 + (long)d.chunk_len, (long)d.nspec);  // (BR: a wave past the last chunk adds zeros)
   const LblAddr ad = lbl_pair_addr(d, p);
 
+  // main.cpp:329: 32 bands per wave pass.  BR (one column): on odd iterations (Dev::flip) the passes run last first.
   const long bf = b0 + PairLbl::index(lane);
-  const int npl = bf < b1 ? (int)((b1 - bf + 31) >> 5) : 0;  // passes of this lane (main.cpp:329: 32 bands per wave pass)
-  for (int i = 0; i < npl; ++i) {
-    const long b = bf + 32L * (d.flip ? npl - 1 - i : i);
+  const long blast = bf + ((b1 - 1 - bf) & ~31L);  // the lane's last band (< bf when it has none)
+  const long bstep = (BR && d.flip) ? -32 : 32;
+  for (long b = (BR && d.flip) ? blast : bf; BR ? (b >= bf && b < b1) : (b < b1); b += bstep) {
     // ---- optical depths of the lane's ten layers (lbl composition + cloud, main.cpp:266-274)
     double tau[NH];
     lbl_pair_tau(s, p, ad.sbase, ad.row0 + (unsigned)b * 8u, ad.rstep, st, lane);
