@@ -658,7 +658,9 @@ __global__ __launch_bounds__(64 * WPB, RCM_PAIR_LB) void k_rt_lbl_pair(Dev d) {
   double(*st)[64] = s_stage[wib];
 
   RCM_PT_STAMP(0);
-  lbl_pair_image(d, col, lane, s);
+  int lane_p = lane;
+  if constexpr (BR) RCM_PRIO_START(lane_p);
+  lbl_pair_image(d, col, lane_p, s);
   __syncthreads();
   RCM_PT_STAMP(1);
   [[maybe_unused]] int pass = 0;  // (stamps only)
@@ -696,7 +698,17 @@ __global__ __launch_bounds__(64 * WPB, RCM_PAIR_LB) void k_rt_lbl_pair(Dev d) {
     for (int k = 0; k < NH; ++k) B[k] = st[k][lane];
     const double Linit = p ? st[NH][lane] : 0.0;  // main.cpp:300-301
     RCM_PT_STAMP(3 + 3 * (pass < 19 ? pass : 19));
-    pair_all_angles<PairLbl, CUBE>(d, tau, B, Linit, st, lane, acc1, acc2);
+    if constexpr (BR) {
+      // one column: the short latency-bound phases of a wave (image, loads, Planck, reduction) run at wave priority 3,
+      // its angle loop at 0 -- they no longer queue behind the partner wave's arithmetic (RT 56.4 - 58.0 -> 54.9 - 55.1 us,
+      // three rounds of an A/B; the 10 000-column kernel, whose waves live for 150 passes, does not care: round 2)
+      double Lin = Linit;
+      RCM_PRIO_LO(Lin);
+      pair_all_angles<PairLbl, CUBE>(d, tau, B, Lin, st, lane, acc1, acc2);
+      RCM_PRIO_HI(acc1[0]);
+    } else {
+      pair_all_angles<PairLbl, CUBE>(d, tau, B, Linit, st, lane, acc1, acc2);
+    }
     RCM_PT_STAMP(4 + 3 * (pass < 19 ? pass : 19));
     ++pass;
   }
