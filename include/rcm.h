@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define RCM_ABI_VERSION 3
+#define RCM_ABI_VERSION 3 /* 3: + rcm_measure_hbm_bandwidth, rcm_set_species_merging (additions only: a caller of 2 runs unchanged) */
 
 #define RCM_OK 0
 #define RCM_ERR_ARG (-1)    /* bad argument / unsupported size            */

@@ -536,6 +536,16 @@ def test_driver_sharded_over_handles_and_gathered(pkg, golden, tmp_path):
     e2 = _run_driver(eq + ["--devices", "0,0", "--output", "q2.txt"], tmp_path)
     n1 = e1.stderr.split(" iterations")[0].split("x ")[-1]
     assert f"x {n1} iterations" in e2.stderr and 25 <= int(n1) < 401
+    # more device entries than columns: the blocks without columns are dropped (rcm_create refuses zero columns), the
+    # two columns land on two handles and the gathered state is the two-column run's
+    few = ["--atm", os.path.join(golden, "test.atm"), "--table", os.path.join(golden, "Reduced10Forcing.rtab"), "--ncol", "2",
+           "--steps", "5", "--output-steps", "100"]
+    f1 = _run_driver(few + ["--gather-out", "f1.txt", "--output", "p1.txt"], tmp_path)
+    f4 = _run_driver(few + ["--devices", "0,0,0,0", "--gather-out", "f4.txt", "--output", "p4.txt"], tmp_path)
+    assert "on 2 handle(s)" in f4.stderr and f1.returncode == f4.returncode == 0
+    a = np.array([[float(v) for v in ln.split(",")] for ln in (tmp_path / "f1.txt").read_text().splitlines()])
+    b = np.array([[float(v) for v in ln.split(",")] for ln in (tmp_path / "f4.txt").read_text().splitlines()])
+    assert a.shape == b.shape == (2, 22) and H.max_abs(a, b) <= 1e-10
 
 
 def test_full_spectrum_step_is_consistent_with_its_own_fluxes(pkg, big):
