@@ -8,10 +8,12 @@
  *
  * The reference is /root/reference (pabloconrat/our_first_climate_model).
  *
- * PARITY UNPINNED for the hot functions (Planck, sweep, read_tau, time step): main.cpp and
- * repwvl_thermal.cpp need <netcdf>, absent from this image, and the reference holds no flux
- * fixture; pinned are the t = 0 rows / solar banners of output.txt and, against the compiled
- * reference, cplkavg and the ASCII loader (rcm_oracle.h, oracle/README.md).
+ * PARITY: pinned bit for bit by the reference's own code compiled here (oracle/build_ref.sh ->
+ * oracle/_ref/: main.cpp's body, read_tau's netCDF-free statements, LowerPos, cplkavg.cpp, ascii.cpp)
+ * and by committed outputs of it (tests/golden/ref_main_vectors.npz) for every function that has a
+ * reference counterpart; UNPINNED by construction: the lbl composition (orc_lbl_tau and the band
+ * convention), for which the reference has no driver and no spectra.  Details: rcm_oracle.h,
+ * oracle/README.md, DESIGN.md section 2.
  */
 #define _GNU_SOURCE
 #include "rcm_oracle.h"

@@ -9,17 +9,17 @@
  * links nor loads it.
  *
  * Parity pinning (see oracle/README.md, DESIGN.md section "Oracle"):
- *   - PINNED, bit for bit, by the reference's own code compiled here from where it lies (oracle/Makefile ->
+ *   - PINNED, bit for bit, by the reference's own code compiled here from where it lies (oracle/build_ref.sh ->
  *     oracle/_ref/libref_main.so = main.cpp:12-21,25-344 unedited + C-linkage call-throughs): Planck,
  *     emissivity, monochromatic_radiative_transfer, radiative_transfer, cloud_into_tau, calculate_timestep,
  *     thermodynamics, adjustment, magnus, water_vapor_feedback, solar set-up (SURVEY.md 8 rows a1-a4, a5',
- *     a6-a8), incl. 101 chained iterations; LowerPos (libref_lowerpos.so); cplkavg.cpp and ascii.cpp as whole
- *     translation units (a10, f1); tests/test_reference_pins.py, tests/test_oracle_pins.py,
+ *     a6-a8), incl. 101 chained iterations; LowerPos (libref_lowerpos.so); read_tau (a5, since round 4:
+ *     libref_readtau.so = every statement of repwvl_thermal.cpp:55-262 that names no netCDF type, unedited, the
+ *     values of the skipped getDim / getVar lines supplied from the same file's datasets); cplkavg.cpp and
+ *     ascii.cpp as whole translation units (a10, f1); tests/test_reference_pins.py, tests/test_oracle_pins.py,
+ *   - the same as committed DATA (tests/golden/ref_main_vectors.npz): holds without the reference tree,
  *   - PINNED by reference-held data: solar banners and the t=0 rows of the reference's output.txt,
- *   - PARITY UNPINNED for the interpolation arithmetic of read_tau (a5, repwvl_thermal.cpp:197-248: it reads
- *     through netCDF::NcVar inside the loop; netcdf-cxx4 is absent and no stand-in header is allowed) --
- *     corroborated only by the outputs SURVEY.md 8(c) recorded (tests/golden/survey_probe.json) -- and for
- *     the lbl composition (a9: no reference driver exists).
+ *   - PARITY UNPINNED, by construction, for the lbl composition (a9: no reference driver, no spectra).
  *
  * Conventions: layer index 0 = top of atmosphere; all arrays row-major;
  * everything double except `time` (float, main.cpp:359).
