@@ -154,7 +154,7 @@ def cpu_baseline(pkg, inp_full, workload, log):
         dt_load = (time.perf_counter() - t0) / 20
         out["single_core_reread_table_per_step_value"] = 1.0 / (dt1 + dt_load)
         ref = ol.load_ref_main()
-        if ref is not None:  # the reference's own radiative_transfer (main.cpp:320-344 compiled by oracle/Makefile)
+        if ref is not None:  # the reference's own radiative_transfer (main.cpp:320-344 compiled by oracle/build_ref.sh)
             t0 = time.perf_counter()
             for _ in range(reps):
                 ol.ref_radiative_transfer(ref, tau, wvl, wgt, Tl, float(st["T_surface"][0]), float(inp_full["solar"]))

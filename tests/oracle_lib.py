@@ -251,7 +251,7 @@ class OracleEnsemble:
         return self.lib.orc_threads_used(self.h)
 
 
-# ---- the reference's own code, compiled from where it lies into oracle/_ref/ (oracle/Makefile) -------------
+# ---- the reference's own code, compiled from where it lies into oracle/_ref/ (oracle/build_ref.sh) -------------
 
 REF_DIR = os.path.join(ROOT, "oracle", "_ref")
 

@@ -825,7 +825,7 @@ def test_accuracy_budget_of_the_planck_functions(variants, olib):
 def test_gpu_against_the_compiled_reference_itself(pkg, olib, golden, table):
     """Not through the oracle: the fluxes, time step and temperatures of the HIP path against main.cpp's own
     radiative_transfer / calculate_timestep / thermodynamics / adjustment / feedback, compiled from where the file
-    lies (oracle/Makefile; tests/test_reference_pins.py has the oracle == that library bit for bit).  test.atm, the
+    lies (oracle/build_ref.sh; tests/test_reference_pins.py has the oracle == that library bit for bit).  test.atm, the
     reference's tables, 101 iterations of the loop body main.cpp:536-581 driven with the reference's functions; the
     one thing the compiled reference cannot supply, read_tau's interpolation, comes (i) from the GPU itself at step 0
     -- the sweep alone, same optical depths on both sides -- and (ii) from the oracle's restatement along the chain.
