@@ -100,6 +100,25 @@ def test_config3_10000_columns_full_lbl_spectrum_sampled_against_oracle(pkg, oli
     _compare_sampled(pkg, olib, inp, [0, 4999, 9999], steps=2)
 
 
+def test_config4_one_gpus_share_of_the_100000_column_run_sampled_against_oracle(pkg, olib):
+    """BASELINE configs[4] at the size ONE of its 8 GPUs sees: rank 3's block of the 100 000-column ensemble (columns
+    37 500 .. 49 999 of the CO2 x RH x T_surface sweep, cut exactly as bench.py / equilibrium_ensemble.py cut it:
+    distributed.shard_bounds + perturbation_sweep(first, total)) x 131 071 bands, 2 steps; six of its columns against
+    the oracle, the identities of main.cpp:337-341 / 156-162 / 173 on all 12 500.  (All eight blocks to equilibrium,
+    one after another on one GPU: profiles/r02_equilibrium_100000_shards.json.)"""
+    from our_first_climate_model_amd.distributed import shard_bounds
+    lo, hi = shard_bounds(100000, 3, 8)
+    assert (lo, hi) == (37500, 50000)
+    atm_cols, _ = pkg.atm_load(os.path.join(H.GOLDEN, "fpda.lbl.atm"))
+    spec = pkg.perturbation_sweep(hi - lo, perturb_rh=True, perturb_ts=True, first=lo, total=100000)
+    cols = pkg.build_columns(atm_cols, spec, "lbl")
+    wvl, tabs = pkg.synth_lbl_tables(131072, plevel=cols["plevel"])
+    inp = dict(mode="lbl", ncol=hi - lo, cols=cols, solar=pkg.default_solar()["solar_irr"], wvl=wvl, tabs=tabs)
+    full = pkg.perturbation_sweep(100000, perturb_rh=True, perturb_ts=True)          # the window IS that part of the sweep
+    assert np.array_equal(spec.co2_factor, full.co2_factor[lo:hi]) and np.array_equal(spec.T_surface0, full.T_surface0[lo:hi])
+    _compare_sampled(pkg, olib, inp, [0, 1, 6249, 6250, 12498, 12499], steps=2)
+
+
 # ---- the fused whole-step kernel of the repwvl path (k_step_repwvl; TEST-SIDE build: measured slower than the
 # three-kernel path, kept as a second complete implementation of the step) ------------------------------------
 @pytest.mark.parametrize("table", ["Reduced10", "Reduced20", "Reduced100"])
