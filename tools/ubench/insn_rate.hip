@@ -18,6 +18,9 @@ __global__ __launch_bounds__(256) void k(int iters, double seed, double *out) {
   const double m = 0.9999999, a = 1e-9;
   for (int it = 0; it < iters; ++it) {
 #define FMA(i) asm volatile("v_fma_f64 %0, %0, %1, %2" : "+v"(v[i]) : "v"(m), "v"(a));
+#define FMAS(i) asm volatile("v_fma_f64 %0, %0, %1, %2" : "+v"(v[i]) : "s"(m), "v"(a));
+#define FMASS(i) asm volatile("v_fma_f64 %0, %0, %1, %1" : "+v"(v[i]) : "s"(m));
+#define FMAD(i) asm volatile("v_fma_f64 %0, %1, %2, %0" : "+v"(v[i]) : "v"(v[(i + 1) & 7]), "v"(v[(i + 2) & 7]));
 #define MUL(i) asm volatile("v_mul_f64 %0, %0, %1" : "+v"(v[i]) : "v"(m));
 #define ADD(i) asm volatile("v_add_f64 %0, %0, %1" : "+v"(v[i]) : "v"(a));
 #define LDEXP(i) asm volatile("v_ldexp_f64 %0, %0, %1" : "+v"(v[i]) : "v"(e));
@@ -51,6 +54,9 @@ __global__ __launch_bounds__(256) void k(int iters, double seed, double *out) {
     if (OP == 14) { BLOCK8(CMPS) }
     if (OP == 15) { BLOCK8(ADDU8) }
     if (OP == 16) { BLOCK8(DPP8) }
+    if (OP == 17) { BLOCK8(FMAS) }
+    if (OP == 18) { BLOCK8(FMASS) }
+    if (OP == 19) { BLOCK8(FMAD) }
   }
   double r = e + (double)(msk & 1);
   for (int i = 0; i < 8; ++i) r += v[i] + w[i];
@@ -75,13 +81,14 @@ int main() {
   double *out;
   (void)hipMalloc(&out, 8);
   const int iters = 20000;
-  const char *names[17] = {"v_fma_f64", "v_mul_f64", "v_add_f64", "v_ldexp_f64", "v_max_f64", "v_mov_b64", "v_rndne_f64",
+  const char *names[20] = {"v_fma_f64", "v_mul_f64", "v_add_f64", "v_ldexp_f64", "v_max_f64", "v_mov_b64", "v_rndne_f64",
                            "v_cvt_i32_f64", "v_add_u32 (1 chain)", "v_rcp_f64", "v_cndmask vcc (8 regs)", "v_mov_b32_dpp (1 chain)",
-                           "v_cndmask sgpr (8 regs)", "v_cmp_lt_f64 vcc", "v_cmp_lt_f64 sgpr", "v_add_u32 (8 regs)", "v_mov_b32_dpp (8 regs)"};
-  float ms[17] = {run<0>(iters, out), run<1>(iters, out), run<2>(iters, out), run<3>(iters, out), run<4>(iters, out), run<5>(iters, out),
+                           "v_cndmask sgpr (8 regs)", "v_cmp_lt_f64 vcc", "v_cmp_lt_f64 sgpr", "v_add_u32 (8 regs)", "v_mov_b32_dpp (8 regs)", "v_fma_f64 v,v,s,v", "v_fma_f64 v,v,s,s", "v_fma_f64 3 distinct vgprs"};
+  float ms[20] = {run<0>(iters, out), run<1>(iters, out), run<2>(iters, out), run<3>(iters, out), run<4>(iters, out), run<5>(iters, out),
                   run<6>(iters, out), run<7>(iters, out), run<8>(iters, out), run<9>(iters, out), run<10>(iters, out), run<11>(iters, out),
-                  run<12>(iters, out), run<13>(iters, out), run<14>(iters, out), run<15>(iters, out), run<16>(iters, out)};
-  for (int i = 0; i < 17; ++i)  // 3 waves per SIMD x 64 instructions per iteration
+                  run<12>(iters, out), run<13>(iters, out), run<14>(iters, out), run<15>(iters, out), run<16>(iters, out),
+                  run<17>(iters, out), run<18>(iters, out), run<19>(iters, out)};
+  for (int i = 0; i < 20; ++i)  // 3 waves per SIMD x 64 instructions per iteration
     printf("%-26s %8.3f ms  = %5.2f ns per instruction per SIMD = %5.2f x v_fma_f64\n", names[i], ms[i],
            ms[i] * 1e6 / iters / (3 * 64), ms[i] / ms[0]);
   return 0;
