@@ -52,6 +52,7 @@ struct rcm_ensemble {
   int lds_pad = 0;  // -DRCM_EXPERIMENT builds: dynamic LDS bytes added to the lbl launch (bounds the blocks per CU)
   int block_records = 1;  // (-DRCM_EXPERIMENT builds read RCM_BLOCK_RECORDS: 0 = the two-stage sum with k_reduce_partials)
   int flip_passes = 1;    // (-DRCM_EXPERIMENT builds read RCM_FLIP: 0 = every launch takes its passes in the same order)
+  int phase_prio = 1;     // (-DRCM_EXPERIMENT builds read RCM_FEW_PRIO: 0 = small ensembles run the plain instantiation)
   std::vector<double> plevel, player, conv;
   std::vector<void *> allocs;
   Dev d{};
@@ -274,6 +275,13 @@ bool use_block_records(const rcm_ensemble *h) {
          h->d.nchunk >= 512 && h->ncol == 1;
 }
 
+// lbl launches of at most this many waves run k_rt_lbl_pair<1, 2>: same arithmetic, but the short latency-bound phases of
+// a wave (image, loads, Planck, reduction) at s_setprio 3 and its angle loop at 0.  Measured in one process
+// (tools/ab_single.py, profiles/r04_lbl_few_columns_phase_priorities.txt), RT launch: 2 columns 92.5 -> 88.7 us (-4 %),
+// 4: 164.7 -> 160.4, 8: 308.7 -> 304.0, 16: 598 -> 591, 64: 2 216 -> 2 199 (-0.8 %); 512 columns (262 144 waves) +0.25 %
+// and 10 000 columns +-0.1 %: beyond ~65 000 waves a wave lives for 8 passes and more and does not care.
+constexpr long kPhasePrioMaxWaves = 65536;
+
 bool use_flat(const rcm_ensemble *h) {
   return h->mode == rcm::MODE_REPWVL && h->flat && h->pair && h->exp_variant == 1 && h->user_chunks == 0 &&
          (long long)h->ncol * h->d.n_wvl < (1ll << 31) - 4096 &&  // 32-bit item arithmetic in the kernel
@@ -340,6 +348,9 @@ void launch_rt_pair(rcm_ensemble *h, int blocks) {
   if (h->mode == rcm::MODE_LBL && CUBE && use_block_records(h)) {
     const int nrec = (h->d.nchunk + rcm::WPB - 1) / rcm::WPB;
     hipLaunchKernelGGL((rcm::k_rt_lbl_pair<1, 1>), dim3((unsigned)(nrec * h->ncol)), dim3(64 * rcm::WPB), 0, h->stream, h->d);
+  } else if (h->mode == rcm::MODE_LBL && CUBE && h->phase_prio && (long)h->ncol * h->d.nchunk <= kPhasePrioMaxWaves) {
+    // small ensembles (waves of a few passes): the instantiation whose phases around the angle loop run at wave priority 3
+    hipLaunchKernelGGL((rcm::k_rt_lbl_pair<1, 2>), dim3(blocks), dim3(64 * rcm::WPB), 0, h->stream, h->d);
   } else if (h->mode == rcm::MODE_LBL) {
 #ifdef RCM_EXPERIMENT
     if (h->lds_pad > 0)
@@ -550,6 +561,7 @@ int rcm_create(int ncol, int nlayer, int nangle, int device, void *stream, rcm_e
   if (const char *v = std::getenv("RCM_LDS_PAD")) h->lds_pad = std::atoi(v);
   if (const char *v = std::getenv("RCM_BLOCK_RECORDS")) h->block_records = std::atoi(v);
   if (const char *v = std::getenv("RCM_FLIP")) h->flip_passes = std::atoi(v);
+  if (const char *v = std::getenv("RCM_FEW_PRIO")) h->phase_prio = std::atoi(v);
 #endif
 #ifdef RCM_WITH_VARIANTS  // kernel selection by environment: test-side library only
   if (const char *v = std::getenv("RCM_EXP_VARIANT")) h->exp_variant = std::atoi(v) ? 1 : 0;

@@ -638,6 +638,9 @@ __device__ __forceinline__ void lbl_pair_planck(const Dev &d, const PairLds &s, 
 // and k_post sums them directly: the k_reduce_partials launch between the two is gone (one column x 131 071 bands:
 // 2 048 -> 512 records, 4.8 us of a 73 us step) and the wave's tail is 21 x 3 DPP steps instead of 21 x 5 butterfly
 // levels, two of which cross rows.
+// BR = 2 (small ensembles, launches of <= 65 536 waves): the plain item mapping and records of BR = 0; like BR = 1 the
+// phases around the angle loop run at wave priority 3 and the loop at 0 (-4 % at 2 columns ... -0.8 % at 64; the
+// 10 000-column launch, whose waves live for 150 passes, does not care and keeps BR = 0).
 template <int CUBE, int BR = 0>
 __global__ __launch_bounds__(64 * WPB, RCM_PAIR_LB) void k_rt_lbl_pair(Dev d) {
   __shared__ PairLds s_col[WPB];
@@ -647,8 +650,9 @@ __global__ __launch_bounds__(64 * WPB, RCM_PAIR_LB) void k_rt_lbl_pair(Dev d) {
   // work item = (chunk, column), column fastest: the waves of a block and neighbouring blocks share
   // the chunk (its table tile stays in L2); a small ensemble still fills every wave slot
   const long nitem = (long)d.ncol * d.nchunk;
-  const long item_raw = BR ? ((long)(blockIdx.x / (unsigned)d.ncol) * WPB + wib) * d.ncol + blockIdx.x % (unsigned)d.ncol
-                           : (long)blockIdx.x * WPB + wib;
+  constexpr bool REC = BR == 1;  // block records (+ flipped pass order); BR >= 1: phase priorities
+  const long item_raw = REC ? ((long)(blockIdx.x / (unsigned)d.ncol) * WPB + wib) * d.ncol + blockIdx.x % (unsigned)d.ncol
+                            : (long)blockIdx.x * WPB + wib;
   const bool valid = item_raw < nitem;
   const long item = valid ? item_raw : nitem - 1;
   const int chunk = (int)(item / d.ncol);
@@ -677,14 +681,14 @@ __global__ __launch_bounds__(64 * WPB, RCM_PAIR_LB) void k_rt_lbl_pair(Dev d) {
   for (int j = 0; j < NH; ++j) acc2[j] = 0.0;
 
   const long b0 = (long)chunk * d.chunk_len;
-  const long b1 = (BR && !valid) ? b0 : min(b0 + (long)d.chunk_len, (long)d.nspec);  // (BR: a wave past the last chunk adds zeros)
+  const long b1 = (REC && !valid) ? b0 : min(b0 + (long)d.chunk_len, (long)d.nspec);  // (REC: a wave past the last chunk adds zeros)
   const LblAddr ad = lbl_pair_addr(d, p);
 
   // main.cpp:329: 32 bands per wave pass.  BR (one column): on odd iterations (Dev::flip) the passes run last first.
   const long bf = b0 + PairLbl::index(lane);
   const long blast = bf + ((b1 - 1 - bf) & ~31L);  // the lane's last band (< bf when it has none)
-  const long bstep = (BR && d.flip) ? -32 : 32;
-  for (long b = (BR && d.flip) ? blast : bf; BR ? (b >= bf && b < b1) : (b < b1); b += bstep) {
+  const long bstep = (REC && d.flip) ? -32 : 32;
+  for (long b = (REC && d.flip) ? blast : bf; REC ? (b >= bf && b < b1) : (b < b1); b += bstep) {
     // ---- optical depths of the lane's ten layers (lbl composition + cloud, main.cpp:266-274)
     double tau[NH];
     lbl_pair_tau(s, p, ad.sbase, ad.row0 + (unsigned)b * 8u, ad.rstep, st, lane);
@@ -713,10 +717,10 @@ __global__ __launch_bounds__(64 * WPB, RCM_PAIR_LB) void k_rt_lbl_pair(Dev d) {
     ++pass;
   }
 
-  if constexpr (!BR) {
+  if constexpr (!REC) {
     store_pair_partial<PairLbl>(d, col, chunk, lane, valid, acc1, acc2);
   } else {
-    static_assert(!BR || RCM_LBL_LAYOUT == 2, "the block reduction assumes Pair<2>: half-rows of 8 lanes alternate in parity");
+    static_assert(!REC || RCM_LBL_LAYOUT == 2, "the block reduction assumes Pair<2>: half-rows of 8 lanes alternate in parity");
     // [wave][half-row of 8 lanes][acc1[0..10], acc2[0..9]], aliased onto the staging rows (the angle loops are over)
     double(*red)[8][2 * NH + 1] = reinterpret_cast<double(*)[8][2 * NH + 1]>(&s_stage[0][0][0]);
     static_assert(sizeof(double) * WPB * 8 * (2 * NH + 1) <= sizeof(s_stage), "reduction rows fit the staging rows");

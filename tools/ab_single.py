@@ -13,7 +13,7 @@ import torch  # noqa: F401
 import helpers as H
 import our_first_climate_model_amd as pkg
 
-inputs = {n: H.make_inputs(pkg, "lbl", n, n_nodes=131072, atm="fpda.lbl.atm") for n in (1, 2, 3, 4, 8, 16)}
+inputs = {n: H.make_inputs(pkg, "lbl", n, n_nodes=131072, atm="fpda.lbl.atm") for n in (1, 2, 3, 4, 8, 16, 64)}
 for rep in range(2):
     for spec in sys.argv[1:]:
         name, _, envs = spec.partition(":")
